@@ -1,0 +1,822 @@
+// Context, weight packing and the launch sequences behind the C ABI (include/uw_hip.h).
+#include "../../include/uw_hip.h"
+#include "uw_common.h"
+#include "uw_kernels.h"
+#include <stdarg.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+void uw_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+size_t uw_dtw_dir_words(int S);
+
+namespace {
+
+struct AttnW {            // one attention block
+    void* wqkv = nullptr; // self: [3d][d] (q*1/8 | k | v); cross: unused
+    float* bqkv = nullptr;
+    void* wq = nullptr;   // cross / encoder: [d][d] q*1/8 ; encoder: [2d][d] (q | k)
+    float* bq = nullptr;
+    void* wkv = nullptr;  // cross: [2d][d] (k | v)
+    float* bkv = nullptr;
+    void* wv = nullptr;   // [d][d] for the transposed-V product
+    float* bv = nullptr;
+    void* wo = nullptr;
+    float* bo = nullptr;
+    float *ln_g = nullptr, *ln_b = nullptr;
+};
+struct LayerW {
+    AttnW self, cross;
+    void *w1 = nullptr, *w2 = nullptr;
+    float *b1 = nullptr, *b2 = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+};
+
+}  // namespace
+
+struct uw_ctx {
+    uw_config cfg;
+    int device = 0;
+    int dt = UW_BF16;
+    size_t es = 2;             // element size of the compute dtype
+    int d = 0, H = 0, S = 0, Spad = 0, Tm = 0, V = 0, Bm = 0, k1pad = 0;
+    long melT_stride = 0;      // elements per window of the time-major mel buffer
+    int64_t bytes = 0;
+    std::vector<void*> allocs;
+    MelTables* mel_tables = nullptr;
+    // encoder weights
+    void *conv1_w = nullptr, *conv2_w = nullptr;
+    float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *enc_ln_g = nullptr, *enc_ln_b = nullptr;
+    std::vector<LayerW> enc, dec;
+    // decoder weights
+    float *tok_emb32 = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
+    void* tok_emb = nullptr;   // [V][d] compute dtype (tied output projection)
+    // alignment heads
+    int n_sel = 0;
+    // workspace: encoder
+    float* mel_max = nullptr;
+    void *melT = nullptr, *h1p = nullptr, *e_ln = nullptr, *e_qk = nullptr, *e_vt = nullptr, *e_attn = nullptr, *e_mlp = nullptr,
+         *enc_T = nullptr;
+    float *e_x = nullptr, *enc_out32 = nullptr;
+    // workspace: decoder
+    void *cross_kv = nullptr, *cross_vt = nullptr, *self_kv = nullptr;
+    void *d_ln = nullptr, *d_qkv = nullptr, *d_vt = nullptr, *d_attn = nullptr, *d_mlp = nullptr;
+    float *d_x = nullptr, *d_last = nullptr, *logits = nullptr, *rows = nullptr;
+    long logits_ld = 0;
+    double* cost = nullptr;
+    uint8_t* dtw_ws = nullptr;
+    int32_t *st_tokens = nullptr, *st_pos = nullptr, *st_n_new = nullptr, *st_n_text = nullptr, *st_active = nullptr,
+            *st_dirty = nullptr, *st_max_new = nullptr, *st_n_active = nullptr, *st_text = nullptr, *st_next = nullptr,
+            *st_qfirst = nullptr, *st_qcount = nullptr, *st_zero = nullptr, *st_ids = nullptr;
+    int32_t* host_pin = nullptr;   // pinned scratch for small read-backs
+    int cross_batch = 0;           // windows covered by the current cross K/V
+    bool enc_valid = false;
+};
+
+namespace {
+
+int dev_alloc(uw_ctx* c, void** p, size_t bytes, bool zero)
+{
+    bytes = (bytes + 255) & ~(size_t)255;
+    UW_HIP_CHECK(hipMalloc(p, bytes));
+    c->allocs.push_back(*p);
+    c->bytes += (int64_t)bytes;
+    if (zero) UW_HIP_CHECK(hipMemset(*p, 0, bytes));
+    return UW_OK;
+}
+#define ALLOC(ptr, bytes, zero)                                         \
+    do {                                                                \
+        int rc__ = dev_alloc(c, (void**)&(ptr), (size_t)(bytes), zero); \
+        if (rc__) return rc__;                                          \
+    } while (0)
+#define RUN(expr)                 \
+    do {                          \
+        int rc__ = (expr);        \
+        if (rc__) return rc__;    \
+    } while (0)
+
+struct Cursor {
+    const void* const* w;
+    int n, i = 0;
+    const float* next() { return (i < n) ? (const float*)w[i++] : (i++, nullptr); }
+};
+
+// dst (compute dtype) rows [row0, row0+rows) of a [*, cols] matrix <- src f32 [rows][cols] * scale
+int pack_rows(uw_ctx* c, void* dst, long row0, const float* src, long rows, long cols, float scale)
+{
+    UW_REQUIRE(src, "weight tensor missing");
+    return uw_convert(c->dt, src, (char*)dst + (size_t)row0 * cols * c->es, rows * cols, scale, 0);
+}
+int copy_f32(float* dst, const float* src, long n, float scale)
+{
+    UW_REQUIRE(src, "weight tensor missing");
+    return uw_convert(UW_F32, src, dst, n, scale, 0);
+}
+
+int load_attn(uw_ctx* c, Cursor& cur, AttnW& a, int kind /*0 enc self, 1 dec self, 2 dec cross*/)
+{
+    const long d = c->d;
+    const float *wq = cur.next(), *bq = cur.next(), *wk = cur.next(), *wv = cur.next(), *bv = cur.next(), *wo = cur.next(),
+                *bo = cur.next(), *lg = cur.next(), *lb = cur.next();
+    UW_REQUIRE(wq && bq && wk && wv && bv && wo && bo && lg && lb, "attention weights missing");
+    if (kind == 1) {
+        ALLOC(a.wqkv, 3 * d * d * c->es, false);
+        ALLOC(a.bqkv, 3 * d * 4, true);
+        RUN(pack_rows(c, a.wqkv, 0, wq, d, d, 0.125f));
+        RUN(pack_rows(c, a.wqkv, d, wk, d, d, 1.f));
+        RUN(pack_rows(c, a.wqkv, 2 * d, wv, d, d, 1.f));
+        RUN(copy_f32(a.bqkv, bq, d, 0.125f));
+        RUN(copy_f32(a.bqkv + 2 * d, bv, d, 1.f));
+        // k|v view for the batched cache-filling product
+        a.wkv = (char*)a.wqkv + (size_t)d * d * c->es;
+        a.bkv = a.bqkv + d;
+        a.wq = a.wqkv;
+        a.bq = a.bqkv;
+    } else if (kind == 0) {
+        ALLOC(a.wq, 2 * d * d * c->es, false);   // q | k
+        ALLOC(a.bq, 2 * d * 4, true);
+        RUN(pack_rows(c, a.wq, 0, wq, d, d, 0.125f));
+        RUN(pack_rows(c, a.wq, d, wk, d, d, 1.f));
+        RUN(copy_f32(a.bq, bq, d, 0.125f));
+    } else {
+        ALLOC(a.wq, d * d * c->es, false);
+        ALLOC(a.bq, d * 4, false);
+        RUN(pack_rows(c, a.wq, 0, wq, d, d, 0.125f));
+        RUN(copy_f32(a.bq, bq, d, 0.125f));
+        ALLOC(a.wkv, 2 * d * d * c->es, false);
+        ALLOC(a.bkv, 2 * d * 4, true);
+        RUN(pack_rows(c, a.wkv, 0, wk, d, d, 1.f));
+        RUN(pack_rows(c, a.wkv, d, wv, d, d, 1.f));
+        RUN(copy_f32(a.bkv + d, bv, d, 1.f));
+    }
+    ALLOC(a.wv, d * d * c->es, false);
+    ALLOC(a.bv, d * 4, false);
+    RUN(pack_rows(c, a.wv, 0, wv, d, d, 1.f));
+    RUN(copy_f32(a.bv, bv, d, 1.f));
+    ALLOC(a.wo, d * d * c->es, false);
+    ALLOC(a.bo, d * 4, false);
+    RUN(pack_rows(c, a.wo, 0, wo, d, d, 1.f));
+    RUN(copy_f32(a.bo, bo, d, 1.f));
+    ALLOC(a.ln_g, d * 4, false);
+    ALLOC(a.ln_b, d * 4, false);
+    RUN(copy_f32(a.ln_g, lg, d, 1.f));
+    RUN(copy_f32(a.ln_b, lb, d, 1.f));
+    return UW_OK;
+}
+
+int load_mlp(uw_ctx* c, Cursor& cur, LayerW& l)
+{
+    const long d = c->d, f = 4 * d;
+    const float *w1 = cur.next(), *b1 = cur.next(), *w2 = cur.next(), *b2 = cur.next(), *lg = cur.next(), *lb = cur.next();
+    UW_REQUIRE(w1 && b1 && w2 && b2 && lg && lb, "mlp weights missing");
+    ALLOC(l.w1, f * d * c->es, false);
+    ALLOC(l.b1, f * 4, false);
+    ALLOC(l.w2, d * f * c->es, false);
+    ALLOC(l.b2, d * 4, false);
+    ALLOC(l.ln2_g, d * 4, false);
+    ALLOC(l.ln2_b, d * 4, false);
+    RUN(pack_rows(c, l.w1, 0, w1, f, d, 1.f));
+    RUN(copy_f32(l.b1, b1, f, 1.f));
+    RUN(pack_rows(c, l.w2, 0, w2, d, f, 1.f));
+    RUN(copy_f32(l.b2, b2, d, 1.f));
+    RUN(copy_f32(l.ln2_g, lg, d, 1.f));
+    RUN(copy_f32(l.ln2_b, lb, d, 1.f));
+    return UW_OK;
+}
+
+int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
+{
+    const uw_config& g = c->cfg;
+    const long d = c->d;
+    const int expect = 5 + g.enc_layers * 15 + 2 + 2 + g.dec_layers * 24 + 2;
+    UW_REQUIRE(n_weights == expect, "expected %d weight tensors for this shape, got %d", expect, n_weights);
+    Cursor cur{weights, n_weights};
+    const float *c1w = cur.next(), *c1b = cur.next(), *c2w = cur.next(), *c2b = cur.next(), *epos = cur.next();
+    UW_REQUIRE(c1w && c1b && c2w && c2b && epos, "conv stem weights missing");
+    ALLOC(c->conv1_w, d * c->k1pad * c->es, false);
+    ALLOC(c->conv2_w, d * 3 * d * c->es, false);
+    ALLOC(c->conv1_b, d * 4, false);
+    ALLOC(c->conv2_b, d * 4, false);
+    ALLOC(c->enc_pos, (long)c->S * d * 4, false);
+    RUN(uw_pack_conv_weight(c->dt, c1w, c->conv1_w, (int)d, g.n_mels, c->k1pad, 0));
+    RUN(uw_pack_conv_weight(c->dt, c2w, c->conv2_w, (int)d, (int)d, (int)(3 * d), 0));
+    RUN(copy_f32(c->conv1_b, c1b, d, 1.f));
+    RUN(copy_f32(c->conv2_b, c2b, d, 1.f));
+    RUN(copy_f32(c->enc_pos, epos, (long)c->S * d, 1.f));
+    c->enc.resize(g.enc_layers);
+    for (auto& l : c->enc) {
+        RUN(load_attn(c, cur, l.self, 0));
+        RUN(load_mlp(c, cur, l));
+    }
+    const float *elg = cur.next(), *elb = cur.next();
+    ALLOC(c->enc_ln_g, d * 4, false);
+    ALLOC(c->enc_ln_b, d * 4, false);
+    RUN(copy_f32(c->enc_ln_g, elg, d, 1.f));
+    RUN(copy_f32(c->enc_ln_b, elb, d, 1.f));
+    const float *temb = cur.next(), *dpos = cur.next();
+    UW_REQUIRE(temb && dpos, "decoder embeddings missing");
+    ALLOC(c->tok_emb32, (long)c->V * d * 4, false);
+    ALLOC(c->dec_pos, (long)c->Tm * d * 4, false);
+    RUN(copy_f32(c->tok_emb32, temb, (long)c->V * d, 1.f));
+    RUN(copy_f32(c->dec_pos, dpos, (long)c->Tm * d, 1.f));
+    if (c->dt == UW_F32) {
+        c->tok_emb = c->tok_emb32;
+    } else {
+        ALLOC(c->tok_emb, (long)c->V * d * c->es, false);
+        RUN(pack_rows(c, c->tok_emb, 0, temb, c->V, d, 1.f));
+    }
+    c->dec.resize(g.dec_layers);
+    for (auto& l : c->dec) {
+        RUN(load_attn(c, cur, l.self, 1));
+        RUN(load_attn(c, cur, l.cross, 2));
+        RUN(load_mlp(c, cur, l));
+    }
+    const float *dlg = cur.next(), *dlb = cur.next();
+    ALLOC(c->dec_ln_g, d * 4, false);
+    ALLOC(c->dec_ln_b, d * 4, false);
+    RUN(copy_f32(c->dec_ln_g, dlg, d, 1.f));
+    RUN(copy_f32(c->dec_ln_b, dlb, d, 1.f));
+    UW_HIP_CHECK(hipDeviceSynchronize());
+    return UW_OK;
+}
+
+int alloc_workspace(uw_ctx* c)
+{
+    const long d = c->d, S = c->S, Bm = c->Bm, Tm = c->Tm, es = (long)c->es, Spad = c->Spad;
+    const uw_config& g = c->cfg;
+    ALLOC(c->mel_max, Bm * 4, true);
+    c->melT_stride = (long)(3000 + 2 + 4) * g.n_mels;   // 2 halo rows + slack for the padded conv1 K
+    ALLOC(c->melT, Bm * c->melT_stride * es, true);
+    ALLOC(c->h1p, Bm * 3002 * d * es, true);
+    ALLOC(c->e_x, Bm * S * d * 4, false);
+    ALLOC(c->e_ln, Bm * S * d * es, false);
+    ALLOC(c->e_qk, Bm * S * 2 * d * es, false);
+    ALLOC(c->e_vt, Bm * d * Spad * es, true);
+    ALLOC(c->e_attn, Bm * S * d * es, false);
+    ALLOC(c->e_mlp, Bm * S * 4 * d * es, false);
+    ALLOC(c->enc_T, Bm * S * d * es, false);
+    ALLOC(c->enc_out32, Bm * S * d * 4, false);
+    const long Ld = g.dec_layers;
+    ALLOC(c->cross_kv, Ld * Bm * S * 2 * d * es, false);
+    ALLOC(c->cross_vt, Ld * Bm * d * Spad * es, true);
+    ALLOC(c->self_kv, Ld * Bm * Tm * 2 * d * es, true);
+    ALLOC(c->d_x, Bm * Tm * d * 4, true);
+    ALLOC(c->d_ln, Bm * Tm * d * es, true);
+    ALLOC(c->d_qkv, Bm * Tm * 3 * d * es, true);
+    ALLOC(c->d_vt, Bm * d * Tm * es, true);
+    ALLOC(c->d_attn, Bm * Tm * d * es, true);
+    ALLOC(c->d_mlp, Bm * Tm * 4 * d * es, true);
+    ALLOC(c->d_last, Bm * d * 4, true);
+    c->logits_ld = (c->V + 3) & ~3;
+    ALLOC(c->logits, Bm * c->logits_ld * 4, true);
+    if (c->n_sel > 0) {
+        ALLOC(c->rows, Bm * (long)c->n_sel * Tm * S * 4, false);
+        ALLOC(c->cost, Bm * Tm * S * 8, false);
+        ALLOC(c->dtw_ws, (size_t)uw_dtw_workspace_bytes((int)Bm, (int)Tm, (int)S), false);
+    }
+    ALLOC(c->st_tokens, Bm * Tm * 4, true);
+    ALLOC(c->st_text, Bm * Tm * 4, true);
+    ALLOC(c->st_ids, Bm * Tm * 4, true);
+    int32_t** small[] = {&c->st_pos, &c->st_n_new, &c->st_n_text, &c->st_active, &c->st_dirty, &c->st_max_new,
+                         &c->st_n_active, &c->st_next, &c->st_qfirst, &c->st_qcount, &c->st_zero};
+    for (auto pp : small) ALLOC(*pp, (Bm + 8) * 4, true);
+    UW_HIP_CHECK(hipHostMalloc((void**)&c->host_pin, (size_t)(8 * Bm + 64) * 4, hipHostMallocDefault));
+    return UW_OK;
+}
+
+// ---- launch sequences -------------------------------------------------------------------------------------
+int gemm(uw_ctx* c, const void* A, long lda, const void* Bw, long ldb, void* C, long ldc, bool out_f32, int M, int N,
+         int K, const float* bias, int act, const float* residual, long ldr, hipStream_t s, int batch = 1, long sA = 0,
+         long sB = 0, long sC = 0, long sR = 0, int bias_mode = 1)
+{
+    GemmParams p;
+    p.A = A; p.B = Bw; p.C = C; p.bias = bias; p.residual = residual;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
+    p.sA = sA; p.sB = sB; p.sC = sC; p.sR = sR;
+    p.M = M; p.N = N; p.K = K; p.batch = batch;
+    p.bias_mode = bias ? bias_mode : 0;
+    p.act = act;
+    return uw_gemm(c->dt, out_f32 ? 1 : 0, p, s);
+}
+
+int encoder_forward(uw_ctx* c, const float* mel, int B, hipStream_t s)
+{
+    const int d = c->d, S = c->S, H = c->H, nm = c->cfg.n_mels;
+    const long M = (long)B * S;
+    RUN(uw_mel_to_time_major(c->dt, mel, c->melT, B, nm, 3000, c->melT_stride, s));
+    // conv1 (k3, pad 1) + GELU: row t of the product reads time-major rows t .. t+2 of the padded mel buffer
+    RUN(gemm(c, c->melT, nm, c->conv1_w, c->k1pad, (char*)c->h1p + (size_t)d * c->es, d, false, 3000, d, c->k1pad, c->conv1_b, 1,
+             nullptr, 0, s, B, c->melT_stride, 0, (long)3002 * d));
+    // conv2 (k3, stride 2, pad 1) + GELU + positions: row t reads padded rows 2t .. 2t+2
+    RUN(gemm(c, c->h1p, 2 * d, c->conv2_w, 3 * d, c->e_x, d, true, S, d, 3 * d, c->conv2_b, 1, c->enc_pos, d, s, B, (long)3002 * d, 0,
+             (long)S * d, 0));
+    for (auto& l : c->enc) {
+        RUN(uw_layernorm(c->dt, c->e_x, c->e_ln, nullptr, l.self.ln_g, l.self.ln_b, M, d, s));
+        RUN(gemm(c, c->e_ln, d, l.self.wq, d, c->e_qk, 2 * d, false, (int)M, 2 * d, d, l.self.bq, 0, nullptr, 0, s));
+        RUN(gemm(c, l.self.wv, d, c->e_ln, d, c->e_vt, c->Spad, false, d, S, d, l.self.bv, 0, nullptr, 0, s, B, 0, (long)S * d,
+                 (long)d * c->Spad, 0, 2));
+        AttnParams a;
+        a.Q = c->e_qk; a.K = (char*)c->e_qk + (size_t)d * c->es; a.VT = c->e_vt; a.O = c->e_attn;
+        a.ldq = a.ldk = 2 * d; a.ldvt = c->Spad; a.ldo = d;
+        a.sQ = a.sK = (long)S * 2 * d; a.sVT = (long)d * c->Spad; a.sO = (long)S * d;
+        a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.causal = 0;
+        RUN(uw_flash_attention(c->dt, a, s));
+        RUN(gemm(c, c->e_attn, d, l.self.wo, d, c->e_x, d, true, (int)M, d, d, l.self.bo, 0, c->e_x, d, s));
+        RUN(uw_layernorm(c->dt, c->e_x, c->e_ln, nullptr, l.ln2_g, l.ln2_b, M, d, s));
+        RUN(gemm(c, c->e_ln, d, l.w1, d, c->e_mlp, 4 * d, false, (int)M, 4 * d, d, l.b1, 1, nullptr, 0, s));
+        RUN(gemm(c, c->e_mlp, 4 * d, l.w2, 4 * d, c->e_x, d, true, (int)M, d, 4 * d, l.b2, 0, c->e_x, d, s));
+    }
+    RUN(uw_layernorm(c->dt, c->e_x, c->enc_T, c->enc_out32, c->enc_ln_g, c->enc_ln_b, M, d, s));
+    c->enc_valid = true;
+    return UW_OK;
+}
+
+size_t cross_kv_layer_bytes(const uw_ctx* c) { return (size_t)c->Bm * c->S * 2 * c->d * c->es; }
+size_t cross_vt_layer_bytes(const uw_ctx* c) { return (size_t)c->Bm * c->d * c->Spad * c->es; }
+size_t self_kv_layer_bytes(const uw_ctx* c) { return (size_t)c->Bm * c->Tm * 2 * c->d * c->es; }
+
+int cross_kv_project(uw_ctx* c, int B, hipStream_t s)
+{
+    const int d = c->d, S = c->S;
+    for (size_t li = 0; li < c->dec.size(); ++li) {
+        auto& a = c->dec[li].cross;
+        void* kv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c);
+        void* vt = (char*)c->cross_vt + li * cross_vt_layer_bytes(c);
+        RUN(gemm(c, c->enc_T, d, a.wkv, d, kv, 2 * d, false, B * S, 2 * d, d, a.bkv, 0, nullptr, 0, s));
+        RUN(gemm(c, a.wv, d, c->enc_T, d, vt, c->Spad, false, d, S, d, a.bv, 0, nullptr, 0, s, B, 0, (long)S * d, (long)d * c->Spad, 0, 2));
+    }
+    c->cross_batch = B;
+    return UW_OK;
+}
+
+__global__ void gather_last_rows_kernel(const float* __restrict__ x, float* __restrict__ out, const int32_t* __restrict__ idx,
+                                        int fixed_idx, int T, int d)
+{
+    const int b = blockIdx.x;
+    int t = idx ? idx[b] : fixed_idx;
+    t = min(max(t, 0), T - 1);
+    const f32x4* src = (const f32x4*)(x + ((long)b * T + t) * d);
+    f32x4* dst = (f32x4*)(out + (long)b * d);
+    for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) dst[i] = src[i];
+}
+
+// Multi-token decoder pass over ids [B][T] (positions 0..T-1); fills the self K/V cache for those positions.
+//   rows_first/rows_count (device, per window) select query rows whose alignment-head probabilities go to c->rows
+//   all_probs: [Ld][B][H][T][S] or null;  logits_all: [B][T][V] or null;  last_idx: device per-window index of the row
+//   whose logits go to c->logits (or fixed_last when null and want_last)
+int decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, const int32_t* rows_first,
+                    const int32_t* rows_count, float* all_probs, float* logits_all, bool want_last, const int32_t* last_idx,
+                    int fixed_last, hipStream_t s)
+{
+    const int d = c->d, S = c->S, H = c->H, Tm = c->Tm;
+    UW_REQUIRE(B > 0 && B <= c->cross_batch, "decoder: batch %d exceeds the %d windows with cross K/V", B, c->cross_batch);
+    UW_REQUIRE(T > 0 && T <= Tm, "decoder: T=%d outside 1..%d", T, Tm);
+    const long M = (long)B * T;
+    const int Tpad = (T + 63) & ~63;
+    RUN(uw_embed_tokens(c->d_x, c->tok_emb32, c->dec_pos, ids, ld_ids, nullptr, B, T, d, c->V, Tm, s));
+    for (size_t li = 0; li < c->dec.size(); ++li) {
+        auto& l = c->dec[li];
+        void* skv = (char*)c->self_kv + li * self_kv_layer_bytes(c);
+        void* ckv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c);
+        void* cvt = (char*)c->cross_vt + li * cross_vt_layer_bytes(c);
+        // --- causal self-attention ---
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.self.ln_g, l.self.ln_b, M, d, s));
+        RUN(gemm(c, c->d_ln, d, l.self.wq, d, c->d_qkv, d, false, (int)M, d, d, l.self.bq, 0, nullptr, 0, s));
+        RUN(gemm(c, c->d_ln, d, l.self.wkv, d, skv, 2 * d, false, T, 2 * d, d, l.self.bkv, 0, nullptr, 0, s, B, (long)T * d, 0,
+                 (long)Tm * 2 * d, 0));
+        RUN(gemm(c, l.self.wv, d, c->d_ln, d, c->d_vt, Tpad, false, d, T, d, l.self.bv, 0, nullptr, 0, s, B, 0, (long)T * d,
+                 (long)d * Tpad, 0, 2));
+        AttnParams a;
+        a.Q = c->d_qkv; a.K = skv; a.VT = c->d_vt; a.O = c->d_attn;
+        a.ldq = d; a.ldk = 2 * d; a.ldvt = Tpad; a.ldo = d;
+        a.sQ = (long)T * d; a.sK = (long)Tm * 2 * d; a.sVT = (long)d * Tpad; a.sO = (long)T * d;
+        a.B = B; a.H = H; a.Sq = T; a.Sk = T; a.causal = 1;
+        RUN(uw_flash_attention(c->dt, a, s));
+        RUN(gemm(c, c->d_attn, d, l.self.wo, d, c->d_x, d, true, (int)M, d, d, l.self.bo, 0, c->d_x, d, s));
+        // --- cross-attention over the encoder frames ---
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.cross.ln_g, l.cross.ln_b, M, d, s));
+        RUN(gemm(c, c->d_ln, d, l.cross.wq, d, c->d_qkv, d, false, (int)M, d, d, l.cross.bq, 0, nullptr, 0, s));
+        ProbParams pp;
+        pp.Q = c->d_qkv; pp.K = ckv; pp.ldq = d; pp.ldk = 2 * d; pp.sQ = (long)T * d; pp.sK = (long)S * 2 * d;
+        pp.B = B; pp.Sq = T; pp.Sk = S;
+        if (rows_count && c->n_sel > 0) {
+            pp.n_heads_sel = 0;
+            for (int k = 0; k < c->n_sel; ++k)
+                if (c->cfg.align_layer[k] == (int)li) { pp.heads[pp.n_heads_sel] = c->cfg.align_head[k]; pp.sel_slot[pp.n_heads_sel++] = k; }
+            if (pp.n_heads_sel > 0) {
+                pp.P = c->rows; pp.sP_b = (long)c->n_sel * Tm * S; pp.sP_sel = (long)Tm * S;
+                pp.q_first = rows_first; pp.q_count = rows_count;
+                RUN(uw_attention_probs(c->dt, pp, s));
+            }
+        }
+        if (all_probs) {
+            pp.q_first = nullptr; pp.q_count = nullptr;
+            pp.sP_b = (long)H * T * S; pp.sP_sel = (long)T * S;
+            float* base = all_probs + (long)li * B * H * T * S;
+            for (int h0 = 0; h0 < H; h0 += 32) {
+                pp.n_heads_sel = std::min(32, H - h0);
+                for (int k = 0; k < pp.n_heads_sel; ++k) { pp.heads[k] = h0 + k; pp.sel_slot[k] = h0 + k; }
+                pp.P = base;
+                RUN(uw_attention_probs(c->dt, pp, s));
+            }
+        }
+        a.Q = c->d_qkv; a.K = ckv; a.VT = cvt; a.O = c->d_attn;
+        a.ldq = d; a.ldk = 2 * d; a.ldvt = c->Spad; a.ldo = d;
+        a.sQ = (long)T * d; a.sK = (long)S * 2 * d; a.sVT = (long)d * c->Spad; a.sO = (long)T * d;
+        a.Sq = T; a.Sk = S; a.causal = 0;
+        RUN(uw_flash_attention(c->dt, a, s));
+        RUN(gemm(c, c->d_attn, d, l.cross.wo, d, c->d_x, d, true, (int)M, d, d, l.cross.bo, 0, c->d_x, d, s));
+        // --- MLP ---
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.ln2_g, l.ln2_b, M, d, s));
+        RUN(gemm(c, c->d_ln, d, l.w1, d, c->d_mlp, 4 * d, false, (int)M, 4 * d, d, l.b1, 1, nullptr, 0, s));
+        RUN(gemm(c, c->d_mlp, 4 * d, l.w2, 4 * d, c->d_x, d, true, (int)M, d, 4 * d, l.b2, 0, c->d_x, d, s));
+    }
+    if (logits_all) {
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, c->dec_ln_g, c->dec_ln_b, M, d, s));
+        RUN(gemm(c, c->d_ln, d, c->tok_emb, d, logits_all, c->V, true, (int)M, c->V, d, nullptr, 0, nullptr, 0, s));
+    }
+    if (want_last) {
+        hipLaunchKernelGGL(gather_last_rows_kernel, dim3(B), dim3(256), 0, s, c->d_x, c->d_last, last_idx, fixed_last, T, d);
+        UW_LAUNCH_CHECK();
+        RUN(uw_layernorm(c->dt, c->d_last, c->d_ln, nullptr, c->dec_ln_g, c->dec_ln_b, B, d, s));
+        RUN(gemm(c, c->d_ln, d, c->tok_emb, d, c->logits, c->logits_ld, true, B, c->V, d, nullptr, 0, nullptr, 0, s));
+    }
+    return UW_OK;
+}
+
+__global__ void embed_step_kernel(float* __restrict__ x, const float* __restrict__ tok_emb, const float* __restrict__ pos_emb,
+                                  const int32_t* __restrict__ tokens, int ld_tok, const int32_t* __restrict__ pos, int d, int vocab,
+                                  int n_ctx)
+{
+    const int b = blockIdx.x;
+    const int p = min(max(pos[b], 0), n_ctx - 1);
+    const int id = min(max(tokens[(long)b * ld_tok + p], 0), vocab - 1);
+    const f32x4* e = (const f32x4*)(tok_emb + (long)id * d);
+    const f32x4* pe = (const f32x4*)(pos_emb + (long)p * d);
+    f32x4* o = (f32x4*)(x + (long)b * d);
+    for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) o[i] = e[i] + pe[i];
+}
+
+// one KV-cached decoder step for the token at st_pos[b] of every active window -> c->logits
+int decoder_step(uw_ctx* c, int B, hipStream_t s)
+{
+    const int d = c->d, S = c->S, H = c->H, Tm = c->Tm;
+    hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, s, c->d_x, c->tok_emb32, c->dec_pos, c->st_tokens, Tm, c->st_pos, d, c->V, Tm);
+    UW_LAUNCH_CHECK();
+    for (size_t li = 0; li < c->dec.size(); ++li) {
+        auto& l = c->dec[li];
+        void* skv = (char*)c->self_kv + li * self_kv_layer_bytes(c);
+        void* ckv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c);
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.self.ln_g, l.self.ln_b, B, d, s));
+        RUN(gemm(c, c->d_ln, d, l.self.wqkv, d, c->d_qkv, 3 * d, false, B, 3 * d, d, l.self.bqkv, 0, nullptr, 0, s));
+        SelfDecodeParams sp;
+        sp.qkv = c->d_qkv; sp.kcache = skv; sp.vcache = (char*)skv + (size_t)d * c->es; sp.out = c->d_attn;
+        sp.pos = c->st_pos; sp.active = c->st_active; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
+        RUN(uw_self_attn_decode(c->dt, sp, s));
+        RUN(gemm(c, c->d_attn, d, l.self.wo, d, c->d_x, d, true, B, d, d, l.self.bo, 0, c->d_x, d, s));
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.cross.ln_g, l.cross.ln_b, B, d, s));
+        RUN(gemm(c, c->d_ln, d, l.cross.wq, d, c->d_qkv, d, false, B, d, d, l.cross.bq, 0, nullptr, 0, s));
+        CrossDecodeParams cp;
+        cp.q = c->d_qkv; cp.K = ckv; cp.V = (char*)ckv + (size_t)d * c->es; cp.out = c->d_attn;
+        cp.rows = c->rows; cp.rows_sB = (long)c->n_sel * Tm * S; cp.rows_sSel = (long)Tm * S;
+        cp.row_index = c->st_n_text; cp.active = c->st_active;
+        for (int h = 0; h < 32; ++h) cp.sel_slot[h] = -1;
+        for (int k = 0; k < c->n_sel; ++k)
+            if (c->cfg.align_layer[k] == (int)li) cp.sel_slot[c->cfg.align_head[k]] = k;
+        cp.B = B; cp.H = H; cp.d = d; cp.S = S; cp.n_rows_max = Tm;
+        RUN(uw_cross_attn_decode(c->dt, cp, s));
+        RUN(gemm(c, c->d_attn, d, l.cross.wo, d, c->d_x, d, true, B, d, d, l.cross.bo, 0, c->d_x, d, s));
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.ln2_g, l.ln2_b, B, d, s));
+        RUN(gemm(c, c->d_ln, d, l.w1, d, c->d_mlp, 4 * d, false, B, 4 * d, d, l.b1, 1, nullptr, 0, s));
+        RUN(gemm(c, c->d_mlp, 4 * d, l.w2, 4 * d, c->d_x, d, true, B, d, 4 * d, l.b2, 0, c->d_x, d, s));
+    }
+    RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, c->dec_ln_g, c->dec_ln_b, B, d, s));
+    RUN(gemm(c, c->d_ln, d, c->tok_emb, d, c->logits, c->logits_ld, true, B, c->V, d, nullptr, 0, nullptr, 0, s));
+    return UW_OK;
+}
+
+__global__ void greedy_init_kernel(GreedyState st, const int32_t* __restrict__ prompt, int ld_prompt,
+                                   const int32_t* __restrict__ plen, int B, int max_tokens, int n_ctx)
+{
+    const int b = blockIdx.x;
+    const int P = plen[b];
+    for (int i = threadIdx.x; i < st.ld_tok; i += blockDim.x) {
+        st.tokens[(long)b * st.ld_tok + i] = (i < P) ? prompt[(long)b * ld_prompt + i] : 0;
+        st.text_ids[(long)b * st.ld_tok + i] = 0;
+    }
+    if (threadIdx.x == 0) {
+        const int budget = max(0, min(max_tokens, n_ctx) - P);
+        st.pos[b] = P - 1;
+        st.n_new[b] = 0;
+        st.n_text[b] = 0;
+        st.dirty_from[b] = -1;
+        st.max_new[b] = budget;
+        st.active[b] = budget > 0 ? 1 : 0;
+        if (budget > 0) atomicAdd(st.n_active, 1);
+    }
+}
+
+// ids_forced[b] = prompt + text[:-1]; q_first = P - 1; q_count = n_text (0 for windows that need no forced pass)
+__global__ void build_forced_ids_kernel(int32_t* __restrict__ ids, int ld, const int32_t* __restrict__ prompt, int ld_prompt,
+                                        const int32_t* __restrict__ plen, const int32_t* __restrict__ text, int ld_text,
+                                        const int32_t* __restrict__ n_text, const int32_t* __restrict__ need,
+                                        int32_t* __restrict__ q_first, int32_t* __restrict__ q_count)
+{
+    const int b = blockIdx.x;
+    const int P = plen[b], N = n_text[b];
+    const bool on = (!need || need[b]) && N > 0;
+    for (int i = threadIdx.x; i < ld; i += blockDim.x) {
+        int v = 0;
+        if (i < P) v = prompt[(long)b * ld_prompt + i];
+        else if (i < P + N - 1) v = text[(long)b * ld_text + (i - P)];
+        ids[(long)b * ld + i] = v;
+    }
+    if (threadIdx.x == 0) {
+        q_first[b] = P - 1;
+        q_count[b] = on ? N : 0;
+    }
+}
+
+__global__ void copy_tokens_out_kernel(const GreedyState st, const int32_t* __restrict__ plen, int32_t* __restrict__ new_tokens,
+                                       int32_t* __restrict__ n_new, int32_t* __restrict__ text_ids, int32_t* __restrict__ n_text,
+                                       int ld_out)
+{
+    const int b = blockIdx.x;
+    const int P = plen[b], nn = st.n_new[b], nt = st.n_text[b];
+    for (int i = threadIdx.x; i < ld_out; i += blockDim.x) {
+        if (new_tokens) new_tokens[(long)b * ld_out + i] = (i < nn) ? st.tokens[(long)b * st.ld_tok + P + i] : 0;
+        if (text_ids) text_ids[(long)b * ld_out + i] = (i < nt) ? st.text_ids[(long)b * st.ld_tok + i] : 0;
+    }
+    if (threadIdx.x == 0) {
+        if (n_new) n_new[b] = nn;
+        if (n_text) n_text[b] = nt;
+    }
+}
+
+__global__ void prompt_rows_kernel(const int32_t* __restrict__ plen, int32_t* __restrict__ q_first, int32_t* __restrict__ q_count, int B)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) { q_first[b] = plen[b] - 1; q_count[b] = 1; }
+}
+
+GreedyState state_of(uw_ctx* c)
+{
+    GreedyState st;
+    st.tokens = c->st_tokens; st.ld_tok = c->Tm; st.pos = c->st_pos; st.n_new = c->st_n_new; st.n_text = c->st_n_text;
+    st.active = c->st_active; st.dirty_from = c->st_dirty; st.max_new = c->st_max_new; st.n_active = c->st_n_active;
+    st.text_ids = c->st_text;
+    return st;
+}
+
+int check_batch(uw_ctx* c, int B)
+{
+    UW_REQUIRE(c, "null context");
+    UW_REQUIRE(B > 0 && B <= c->Bm, "batch %d outside 1..max_batch=%d", B, c->Bm);
+    return UW_OK;
+}
+
+int forced_rows(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const int32_t* plen_dev, const int32_t* text_ids,
+                int ld_text, const int32_t* n_text_dev, const int32_t* need_dev, int B, int T, hipStream_t s)
+{
+    hipLaunchKernelGGL(build_forced_ids_kernel, dim3(B), dim3(256), 0, s, c->st_ids, c->Tm, prompt_ids, ld_prompt, plen_dev, text_ids,
+                       ld_text, n_text_dev, need_dev, c->st_qfirst, c->st_qcount);
+    UW_LAUNCH_CHECK();
+    return decoder_forward(c, c->st_ids, c->Tm, B, T, c->st_qfirst, c->st_qcount, nullptr, nullptr, false, nullptr, 0, s);
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* uw_last_error(void) { return g_err; }
+int uw_abi_version(void) { return 1; }
+
+int uw_ctx_create(const uw_config* cfg, const void* const* weights, int n_weights, const float* mel_filters, uw_ctx** out)
+{
+    UW_REQUIRE(cfg && weights && mel_filters && out, "uw_ctx_create: null argument");
+    UW_REQUIRE(cfg->d_model > 0 && cfg->d_model % 64 == 0 && cfg->n_heads * 64 == cfg->d_model,
+               "d_model=%d must be n_heads(%d) * 64", cfg->d_model, cfg->n_heads);
+    UW_REQUIRE(cfg->d_model <= 2048 && cfg->n_heads <= 32, "d_model=%d too large", cfg->d_model);
+    UW_REQUIRE(cfg->dtype == UW_DTYPE_F32 || cfg->dtype == UW_DTYPE_BF16, "unknown dtype %d", cfg->dtype);
+    UW_REQUIRE(cfg->n_audio_ctx == 1500 && cfg->n_text_ctx > 0 && cfg->n_text_ctx <= 448 && cfg->n_text_ctx % 64 == 0,
+               "n_audio_ctx must be 1500 and n_text_ctx a multiple of 64 up to 448 (got %d, %d)", cfg->n_audio_ctx, cfg->n_text_ctx);
+    UW_REQUIRE(cfg->n_mels == 80 || cfg->n_mels == 128, "n_mels=%d unsupported", cfg->n_mels);
+    UW_REQUIRE(cfg->max_batch > 0 && cfg->max_batch <= 4096, "max_batch=%d", cfg->max_batch);
+    UW_REQUIRE(cfg->n_align_heads >= 0 && cfg->n_align_heads <= UW_MAX_ALIGN_HEADS, "n_align_heads=%d", cfg->n_align_heads);
+    for (int k = 0; k < cfg->n_align_heads; ++k)
+        UW_REQUIRE(cfg->align_layer[k] >= 0 && cfg->align_layer[k] < cfg->dec_layers && cfg->align_head[k] >= 0 &&
+                       cfg->align_head[k] < cfg->n_heads,
+                   "alignment head %d = (%d, %d) out of range", k, cfg->align_layer[k], cfg->align_head[k]);
+    uw_ctx* c = new uw_ctx();
+    c->cfg = *cfg;
+    c->dt = cfg->dtype;
+    c->es = uw_elem_size(c->dt);
+    c->d = cfg->d_model; c->H = cfg->n_heads; c->S = cfg->n_audio_ctx; c->Spad = (c->S + 63) & ~63; c->Tm = cfg->n_text_ctx;
+    c->V = cfg->vocab; c->Bm = cfg->max_batch; c->n_sel = cfg->n_align_heads;
+    const int kt = c->dt == UW_F32 ? 32 : 64;
+    c->k1pad = ((3 * cfg->n_mels + kt - 1) / kt) * kt;
+    int rc = UW_OK;
+    if (hipGetDevice(&c->device) != hipSuccess) { uw_set_error("no HIP device"); rc = UW_ERR_HIP; }
+    if (!rc) rc = uw_mel_tables_create(cfg->n_mels, mel_filters, &c->mel_tables);
+    if (!rc) rc = load_weights(c, weights, n_weights);
+    if (!rc) rc = alloc_workspace(c);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) { uw_set_error("device error during context creation"); rc = UW_ERR_HIP; }
+    if (rc) { uw_ctx_destroy(c); return rc; }
+    *out = c;
+    return UW_OK;
+}
+
+int uw_ctx_destroy(uw_ctx* c)
+{
+    if (!c) return UW_OK;
+    (void)hipDeviceSynchronize();
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->host_pin) (void)hipHostFree(c->host_pin);
+    uw_mel_tables_destroy(c->mel_tables);
+    delete c;
+    return UW_OK;
+}
+
+int64_t uw_ctx_bytes(const uw_ctx* c) { return c ? c->bytes : 0; }
+
+int uw_mel(uw_ctx* c, const float* audio, int64_t stride, const int32_t* n_samples, int B, float* mel_out, void* stream)
+{
+    RUN(check_batch(c, B));
+    return uw_mel_run(c->mel_tables, audio, (long)stride, n_samples, B, mel_out, c->mel_max, (hipStream_t)stream);
+}
+
+int uw_encode(uw_ctx* c, const float* mel, int B, float* enc_out, void* stream)
+{
+    RUN(check_batch(c, B));
+    UW_REQUIRE(mel, "uw_encode: null mel");
+    hipStream_t s = (hipStream_t)stream;
+    RUN(encoder_forward(c, mel, B, s));
+    if (enc_out)
+        UW_HIP_CHECK(hipMemcpyAsync(enc_out, c->enc_out32, (size_t)B * c->S * c->d * 4, hipMemcpyDeviceToDevice, s));
+    return UW_OK;
+}
+
+int uw_cross_kv(uw_ctx* c, const float* enc_states, int B, void* stream)
+{
+    RUN(check_batch(c, B));
+    hipStream_t s = (hipStream_t)stream;
+    if (enc_states) {
+        RUN(uw_convert(c->dt, enc_states, c->enc_T, (long)B * c->S * c->d, 1.f, s));
+    } else {
+        UW_REQUIRE(c->enc_valid, "uw_cross_kv: no encoder output in the context");
+    }
+    return cross_kv_project(c, B, s);
+}
+
+int uw_decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, float* logits_all, float* logits_last,
+                       float* cross_probs, void* stream)
+{
+    RUN(check_batch(c, B));
+    UW_REQUIRE(ids && ld_ids >= T, "uw_decoder_forward: bad ids");
+    hipStream_t s = (hipStream_t)stream;
+    RUN(decoder_forward(c, ids, ld_ids, B, T, nullptr, nullptr, cross_probs, logits_all, logits_last != nullptr, nullptr, T - 1, s));
+    if (logits_last)
+        UW_HIP_CHECK(hipMemcpy2DAsync(logits_last, (size_t)c->V * 4, c->logits, (size_t)c->logits_ld * 4, (size_t)c->V * 4, B,
+                                      hipMemcpyDeviceToDevice, s));
+    return UW_OK;
+}
+
+int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const int32_t* prompt_len_host, int B, int max_tokens,
+                     int eot, int sot, int ts_begin, int ts_end, int32_t* new_tokens, int32_t* n_new, int32_t* text_ids,
+                     int32_t* n_text, void* stream)
+{
+    RUN(check_batch(c, B));
+    UW_REQUIRE(prompt_ids && prompt_len_host, "uw_decode_greedy: null prompt");
+    UW_REQUIRE(B <= c->cross_batch, "uw_decode_greedy: call uw_cross_kv for these %d windows first", B);
+    hipStream_t s = (hipStream_t)stream;
+    int Pmax = 0, Pmin = 1 << 30;
+    for (int b = 0; b < B; ++b) { Pmax = std::max(Pmax, prompt_len_host[b]); Pmin = std::min(Pmin, prompt_len_host[b]); }
+    UW_REQUIRE(Pmin >= 1 && Pmax <= c->Tm && Pmax <= ld_prompt, "prompt lengths must be within 1..%d (got %d..%d)", c->Tm, Pmin, Pmax);
+    int32_t* plen_dev = c->st_zero;   // per-window prompt lengths
+    memcpy(c->host_pin, prompt_len_host, (size_t)B * 4);
+    UW_HIP_CHECK(hipMemcpyAsync(plen_dev, c->host_pin, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    UW_HIP_CHECK(hipMemsetAsync(c->st_n_active, 0, 4, s));
+    GreedyState st = state_of(c);
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(B), dim3(256), 0, s, st, prompt_ids, ld_prompt, plen_dev, B, max_tokens, c->Tm);
+    UW_LAUNCH_CHECK();
+    const int max_steps = std::max(0, std::min(max_tokens, c->Tm) - Pmin);
+    int32_t* h_active = c->host_pin + 4 * c->Bm;
+    if (max_steps > 0) {
+        // prompt pass: fills the self K/V cache, captures attention row 0, gives the logits of the last prompt position
+        hipLaunchKernelGGL(prompt_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, s, plen_dev, c->st_qfirst, c->st_qcount, B);
+        UW_LAUNCH_CHECK();
+        RUN(decoder_forward(c, c->st_tokens, c->Tm, B, Pmax, c->st_qfirst, c->st_qcount, nullptr, nullptr, true, c->st_pos, 0, s));
+        for (int step = 0; step < max_steps; ++step) {
+            if (step > 0) RUN(decoder_step(c, B, s));
+            RUN(uw_argmax_rows(c->logits, c->logits_ld, B, c->V, c->st_next, s));
+            RUN(uw_greedy_advance(st, c->st_next, B, eot, sot, ts_begin, ts_end, s));
+            if ((step & 7) == 7 && step + 1 < max_steps) {
+                UW_HIP_CHECK(hipMemcpyAsync(h_active, c->st_n_active, 4, hipMemcpyDeviceToHost, s));
+                UW_HIP_CHECK(hipStreamSynchronize(s));
+                if (*h_active <= 0) break;
+            }
+        }
+    }
+    // which windows carry text after a generated non-text token?  Their captured rows differ from the reference's
+    // replay (align.py:605-623 feeds prompt + TEXT tokens only), so they get a teacher-forced pass.
+    int32_t *h_ntext = c->host_pin, *h_dirty = c->host_pin + c->Bm, *h_need = c->host_pin + 2 * c->Bm;
+    UW_HIP_CHECK(hipMemcpyAsync(h_ntext, c->st_n_text, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    UW_HIP_CHECK(hipMemcpyAsync(h_dirty, c->st_dirty, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    UW_HIP_CHECK(hipStreamSynchronize(s));
+    int T_forced = 0;
+    for (int b = 0; b < B; ++b) {
+        h_need[b] = (h_dirty[b] >= 0 && h_ntext[b] > h_dirty[b]) ? 1 : 0;
+        if (h_need[b]) T_forced = std::max(T_forced, prompt_len_host[b] + h_ntext[b] - 1);
+    }
+    if (T_forced > 0 && c->n_sel > 0) {
+        UW_HIP_CHECK(hipMemcpyAsync(c->st_max_new, h_need, (size_t)B * 4, hipMemcpyHostToDevice, s));
+        RUN(forced_rows(c, c->st_tokens, c->Tm, plen_dev, c->st_text, c->Tm, c->st_n_text, c->st_max_new, B, std::min(T_forced, c->Tm), s));
+    }
+    hipLaunchKernelGGL(copy_tokens_out_kernel, dim3(B), dim3(256), 0, s, st, plen_dev, new_tokens, n_new, text_ids, n_text, c->Tm);
+    UW_LAUNCH_CHECK();
+    UW_HIP_CHECK(hipStreamSynchronize(s));
+    return UW_OK;
+}
+
+int uw_attn_rows_forced(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const int32_t* prompt_len_host,
+                        const int32_t* text_ids, int ld_text, const int32_t* n_text_host, int B, void* stream)
+{
+    RUN(check_batch(c, B));
+    UW_REQUIRE(prompt_ids && prompt_len_host && text_ids && n_text_host, "uw_attn_rows_forced: null argument");
+    UW_REQUIRE(c->n_sel > 0, "uw_attn_rows_forced: the context has no alignment heads");
+    hipStream_t s = (hipStream_t)stream;
+    int T = 0;
+    for (int b = 0; b < B; ++b) {
+        UW_REQUIRE(prompt_len_host[b] >= 1 && n_text_host[b] >= 0 && prompt_len_host[b] + n_text_host[b] - 1 <= c->Tm &&
+                       prompt_len_host[b] <= ld_prompt && n_text_host[b] <= ld_text,
+                   "window %d: prompt %d + text %d does not fit %d positions", b, prompt_len_host[b], n_text_host[b], c->Tm);
+        T = std::max(T, prompt_len_host[b] + std::max(n_text_host[b], 1) - 1);
+    }
+    memcpy(c->host_pin, prompt_len_host, (size_t)B * 4);
+    memcpy(c->host_pin + c->Bm, n_text_host, (size_t)B * 4);
+    UW_HIP_CHECK(hipMemcpyAsync(c->st_zero, c->host_pin, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    UW_HIP_CHECK(hipMemcpyAsync(c->st_n_text, c->host_pin + c->Bm, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    RUN(forced_rows(c, prompt_ids, ld_prompt, c->st_zero, text_ids, ld_text, c->st_n_text, nullptr, B, T, s));
+    UW_HIP_CHECK(hipStreamSynchronize(s));   // host_pin is reused by the next call
+    return UW_OK;
+}
+
+int uw_get_attn_rows(uw_ctx* c, int B, int n_rows, float* rows, void* stream)
+{
+    RUN(check_batch(c, B));
+    UW_REQUIRE(rows && n_rows > 0 && n_rows <= c->Tm && c->n_sel > 0, "uw_get_attn_rows: bad arguments");
+    UW_HIP_CHECK(hipMemcpy2DAsync(rows, (size_t)n_rows * c->S * 4, c->rows, (size_t)c->Tm * c->S * 4, (size_t)n_rows * c->S * 4,
+                                  (size_t)B * c->n_sel, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return UW_OK;
+}
+
+int uw_cost_matrix(const float* rows, int n_sel, const int32_t* n_tok, int B, int n_rows_max, int S, double* cost, void* stream)
+{
+    return uw_cost_matrix_run(rows, (long)n_sel * n_rows_max * S, (long)n_rows_max * S, n_sel, n_tok, B, n_rows_max, S, cost,
+                              (hipStream_t)stream);
+}
+
+int64_t uw_dtw_workspace_bytes(int B, int n_rows_max, int S)
+{
+    return (int64_t)B * n_rows_max * (int64_t)uw_dtw_dir_words(S) * 4;
+}
+
+int uw_dtw(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, void* dir_ws, int32_t* boundaries,
+           int32_t* path_i, int32_t* path_j, int32_t* path_len, void* stream)
+{
+    return uw_dtw_run(cost, n_tok, B, n_rows_max, S, (uint8_t*)dir_ws, boundaries, path_i, path_j, path_len, (hipStream_t)stream);
+}
+
+int uw_align(uw_ctx* c, const int32_t* n_text, int B, int32_t* boundaries, void* stream)
+{
+    RUN(check_batch(c, B));
+    UW_REQUIRE(n_text && boundaries && c->n_sel > 0, "uw_align: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    RUN(uw_cost_matrix_run(c->rows, (long)c->n_sel * c->Tm * c->S, (long)c->Tm * c->S, c->n_sel, n_text, B, c->Tm, c->S, c->cost, s));
+    return uw_dtw_run(c->cost, n_text, B, c->Tm, c->S, c->dtw_ws, boundaries, nullptr, nullptr, nullptr, s);
+}
+
+int uw_transcribe_windows(uw_ctx* c, const float* audio, int64_t stride, const int32_t* n_samples, const int32_t* prompt_ids,
+                          int ld_prompt, const int32_t* prompt_len_host, int B, int max_tokens, int eot, int sot, int ts_begin,
+                          int ts_end, int32_t* new_tokens, int32_t* n_new, int32_t* text_ids, int32_t* n_text,
+                          int32_t* boundaries, void* stream)
+{
+    RUN(check_batch(c, B));
+    UW_REQUIRE(audio && n_samples && n_text && boundaries, "uw_transcribe_windows: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    // the log-mel tile is parked in the (not yet used) decoder MLP scratch
+    float* mel = (float*)c->e_mlp;
+    RUN(uw_mel_run(c->mel_tables, audio, (long)stride, n_samples, B, mel, c->mel_max, s));
+    RUN(encoder_forward(c, mel, B, s));
+    RUN(cross_kv_project(c, B, s));
+    RUN(uw_decode_greedy(c, prompt_ids, ld_prompt, prompt_len_host, B, max_tokens, eot, sot, ts_begin, ts_end, new_tokens, n_new,
+                         text_ids, n_text, stream));
+    return uw_align(c, n_text, B, boundaries, stream);
+}
+
+}  // extern "C"

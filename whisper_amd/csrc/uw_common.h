@@ -1,0 +1,98 @@
+// Shared device/host helpers for the gfx950 transcription kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define UW_OK 0
+#define UW_ERR_ARG 1
+#define UW_ERR_HIP 2
+#define UW_ERR_STATE 3
+#define UW_ERR_NOPATH 4
+
+void uw_set_error(const char* fmt, ...);
+
+#define UW_HIP_CHECK(expr)                                                                            \
+    do {                                                                                              \
+        hipError_t e__ = (expr);                                                                      \
+        if (e__ != hipSuccess) {                                                                      \
+            uw_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return UW_ERR_HIP;                                                                        \
+        }                                                                                             \
+    } while (0)
+
+#define UW_REQUIRE(cond, ...)          \
+    do {                               \
+        if (!(cond)) {                 \
+            uw_set_error(__VA_ARGS__); \
+            return UW_ERR_ARG;         \
+        }                              \
+    } while (0)
+
+#define UW_LAUNCH_CHECK() UW_HIP_CHECK(hipGetLastError())
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// low / high bf16 of a packed 32-bit word, widened exactly
+__device__ __forceinline__ float bf16lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// A 16-byte K-chunk of an MFMA operand: 8 bf16 or 4 f32.  One call consumes the chunk held by every
+// lane: for the 16x16 shapes the four 16-lane groups hold four consecutive chunks of K, for the 32x32
+// shapes the two 32-lane halves hold two.  The f32 forms split a chunk over four K=4 / K=2 MFMAs, which
+// permutes K inside the chunk group identically for both operands.
+template <typename T> __device__ __forceinline__ void mma16(const uint4& a, const uint4& b, f32x4& acc);
+template <> __device__ __forceinline__ void mma16<bf16_t>(const uint4& a, const uint4& b, f32x4& acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(const uint4& a, const uint4& b, f32x4& acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+template <typename T> __device__ __forceinline__ void mma32(const uint4& a, const uint4& b, f32x16& acc);
+template <> __device__ __forceinline__ void mma32<bf16_t>(const uint4& a, const uint4& b, f32x16& acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma32<float>(const uint4& a, const uint4& b, f32x16& acc)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,295 @@
+// Single-token (KV-cached) decoder attention and the greedy bookkeeping step.
+//
+// The reference re-runs the whole decoder over the whole prefix for every token (urro_whisper/core.py:938-968)
+// and once more per text token to read the cross-attention weights (urro_whisper/align.py:607-623).  Here one
+// step touches each cached K/V element once: per generated token and window the cross-attention K/V of all
+// layers (Ld * 2 * 1500 * d elements) is the dominant HBM stream, and the cross-attention kernel writes the
+// softmax row of the alignment heads straight into the rows buffer that DTW consumes.
+//
+// Both kernels are bandwidth kernels on the vector ALU: a K/V row of one head is 64 elements; LPR lanes
+// (8 for bf16, 16 for f32) each own one 16-byte chunk of a row, so one wave instruction moves 1 KiB.
+#include "uw_common.h"
+#include "uw_kernels.h"
+
+namespace {
+
+template <typename T> struct Row {
+    static constexpr int E = 16 / (int)sizeof(T);   // elements per lane
+    static constexpr int LPR = 64 / E;              // lanes per row
+    static constexpr int RPI = 64 / LPR;            // rows per wave instruction
+};
+
+template <typename T> __device__ __forceinline__ void unpack(const uint4& u, float* f);
+template <> __device__ __forceinline__ void unpack<float>(const uint4& u, float* f)
+{
+    f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y); f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+}
+template <> __device__ __forceinline__ void unpack<bf16_t>(const uint4& u, float* f)
+{
+    f[0] = bf16lo(u.x); f[1] = bf16hi(u.x); f[2] = bf16lo(u.y); f[3] = bf16hi(u.y);
+    f[4] = bf16lo(u.z); f[5] = bf16hi(u.z); f[6] = bf16lo(u.w); f[7] = bf16hi(u.w);
+}
+
+template <typename T> __device__ __forceinline__ float dot_chunk(const uint4& u, const float* q)
+{
+    float f[Row<T>::E];
+    unpack<T>(u, f);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < Row<T>::E; ++e) s = fmaf(f[e], q[e], s);
+    return s;
+}
+
+// sum over the LPR lanes that share a row
+template <typename T> __device__ __forceinline__ float row_sum(float v)
+{
+#pragma unroll
+    for (int o = 1; o < Row<T>::LPR; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-attention for one new token: grid (H, B), 256 threads
+template <typename T>
+__global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
+{
+    using R = Row<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = (float*)smem;                 // [S rounded up] scores, then probabilities
+    const int S = p.S, Spad = (S + 63) & ~63;
+    float* red = sc + Spad;                   // [8]
+    float* part = red + 8;                    // [4 waves][64]
+    const int h = blockIdx.x, b = blockIdx.y;
+    if (p.active && !p.active[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sub = lane % R::LPR, rin = lane / R::LPR;
+    const long ld = p.d;
+    const T* Kh = (const T*)p.K + (long)b * S * ld + h * 64 + sub * R::E;
+    const T* Vh = (const T*)p.V + (long)b * S * ld + h * 64 + sub * R::E;
+
+    float q[R::E];
+    {
+        const T* qp = (const T*)p.q + (long)b * p.d + h * 64 + sub * R::E;
+#pragma unroll
+        for (int e = 0; e < R::E; ++e) q[e] = to_f32<T>(qp[e]);
+    }
+    // ---- scores ----
+    constexpr int U = 8;                               // loads in flight per lane
+    const int rows_per_round = 4 * R::RPI * U;         // rows covered by the workgroup per unrolled round
+    for (int r0 = 0; r0 < S; r0 += rows_per_round) {
+        uint4 kv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            kv[u] = *(const uint4*)(Kh + (long)min(r, S - 1) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            const float s = row_sum<T>(dot_chunk<T>(kv[u], q));
+            if (sub == 0 && r < S) sc[r] = s;
+        }
+    }
+    __syncthreads();
+    // ---- softmax over S ----
+    float mx = -INFINITY;
+    for (int j = tid; j < S; j += 256) mx = fmaxf(mx, sc[j]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < S; j += 256) {
+        const float e = __expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    const int slot = p.sel_slot[h];
+    float* row_out = nullptr;
+    if (p.rows && slot >= 0) {
+        const int ri = p.row_index[b];
+        if (ri >= 0 && ri < p.n_rows_max) row_out = p.rows + (long)b * p.rows_sB + (long)slot * p.rows_sSel + (long)ri * S;
+    }
+    for (int j = tid; j < S; j += 256) {
+        const float pr = sc[j] * inv;
+        sc[j] = pr;
+        if (row_out) row_out[j] = pr;
+    }
+    __syncthreads();
+    // ---- weighted sum of V ----
+    float acc[R::E];
+#pragma unroll
+    for (int e = 0; e < R::E; ++e) acc[e] = 0.f;
+    for (int r0 = 0; r0 < S; r0 += rows_per_round) {
+        uint4 vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            vv[u] = *(const uint4*)(Vh + (long)min(r, S - 1) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            const float w = (r < S) ? sc[r] : 0.f;
+            float f[R::E];
+            unpack<T>(vv[u], f);
+#pragma unroll
+            for (int e = 0; e < R::E; ++e) acc[e] = fmaf(w, f[e], acc[e]);
+        }
+    }
+    // reduce over the RPI row slots of the wave (lanes with equal `sub`), then over the 4 waves
+#pragma unroll
+    for (int e = 0; e < R::E; ++e) {
+#pragma unroll
+        for (int o = R::LPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    }
+    if (rin == 0) {
+#pragma unroll
+        for (int e = 0; e < R::E; ++e) part[wave * 64 + sub * R::E + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float o = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+        ((T*)p.out)[(long)b * p.d + h * 64 + tid] = from_f32<T>(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// causal self-attention for one new token: grid (H, B), one wave; also appends this token's K/V to the cache
+template <typename T>
+__global__ __launch_bounds__(64) void self_decode_kernel(SelfDecodeParams p)
+{
+    using R = Row<T>;
+    __shared__ float sc[512];
+    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    if (p.active && !p.active[b]) return;
+    const int pos = p.pos[b];
+    if (pos < 0 || pos >= p.n_ctx || pos >= 512) return;
+    const int sub = lane % R::LPR, rin = lane / R::LPR;
+    const long ld = p.d;
+    const T* qkv = (const T*)p.qkv + (long)b * 3 * p.d + h * 64 + sub * R::E;
+    T* Kc = (T*)p.kcache + (long)b * p.n_ctx * ld + h * 64 + sub * R::E;
+    T* Vc = (T*)p.vcache + (long)b * p.n_ctx * ld + h * 64 + sub * R::E;
+    const uint4 knew = *(const uint4*)(qkv + p.d), vnew = *(const uint4*)(qkv + 2 * p.d);
+    if (rin == 0) {
+        *(uint4*)(Kc + (long)pos * ld) = knew;
+        *(uint4*)(Vc + (long)pos * ld) = vnew;
+    }
+    float q[R::E];
+#pragma unroll
+    for (int e = 0; e < R::E; ++e) q[e] = to_f32<T>(qkv[e]);
+    const int n = pos + 1;
+    for (int r0 = 0; r0 < n; r0 += R::RPI) {
+        const int r = r0 + rin;
+        uint4 kv = knew;
+        if (r < pos) kv = *(const uint4*)(Kc + (long)r * ld);
+        const float s = row_sum<T>(dot_chunk<T>(kv, q));
+        if (sub == 0 && r < n) sc[r] = s;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, sc[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        const float e = __expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    const float inv = 1.0f / wave_sum(sum);
+    __syncthreads();
+    float acc[R::E];
+#pragma unroll
+    for (int e = 0; e < R::E; ++e) acc[e] = 0.f;
+    for (int r0 = 0; r0 < n; r0 += R::RPI) {
+        const int r = r0 + rin;
+        uint4 vv = vnew;
+        if (r < pos) vv = *(const uint4*)(Vc + (long)r * ld);
+        const float w = (r < n) ? sc[r] * inv : 0.f;
+        float f[R::E];
+        unpack<T>(vv, f);
+#pragma unroll
+        for (int e = 0; e < R::E; ++e) acc[e] = fmaf(w, f[e], acc[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < R::E; ++e) {
+#pragma unroll
+        for (int o = R::LPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    }
+    if (rin == 0) {
+        T* o = (T*)p.out + (long)b * p.d + h * 64 + sub * R::E;
+#pragma unroll
+        for (int e = 0; e < R::E; ++e) o[e] = from_f32<T>(acc[e]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one thread per window: urro_whisper/core.py:959-968 (stop on eot without appending, budget) and :991 (text filter)
+__global__ void greedy_advance_kernel(GreedyState st, const int32_t* __restrict__ next_tok, int B, int eot, int sot,
+                                      int ts_begin, int ts_end)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B || !st.active[b]) return;
+    const int tok = next_tok[b];
+    bool alive = true;
+    if (tok == eot) {
+        alive = false;
+    } else {
+        const int idx = st.pos[b] + 1;   // pos = index of the token that produced these logits
+        st.tokens[(long)b * st.ld_tok + idx] = tok;
+        st.pos[b] = idx;
+        const int nn = st.n_new[b] + 1;
+        st.n_new[b] = nn;
+        const bool is_text = tok < sot && !(tok >= ts_begin && tok <= ts_end);
+        if (is_text) {
+            const int nt = st.n_text[b];
+            st.text_ids[(long)b * st.ld_tok + nt] = tok;
+            st.n_text[b] = nt + 1;
+        } else if (st.dirty_from[b] < 0) {
+            st.dirty_from[b] = st.n_text[b];  // rows captured from here on see a context the reference never builds
+        }
+        if (nn >= st.max_new[b]) alive = false;
+    }
+    if (!alive) {
+        st.active[b] = 0;
+        atomicSub(st.n_active, 1);
+    }
+}
+
+}  // namespace
+
+int uw_cross_attn_decode(int dtype, const CrossDecodeParams& p, hipStream_t s)
+{
+    UW_REQUIRE(p.q && p.K && p.V && p.out && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.S > 0 && p.S <= 4096,
+               "cross_attn_decode: bad arguments");
+    UW_REQUIRE(!p.rows || p.row_index, "cross_attn_decode: rows without row_index");
+    const size_t lds = (size_t)(((p.S + 63) & ~63) + 8 + 256) * 4;
+    const dim3 grid(p.H, p.B);
+    if (dtype == UW_F32) hipLaunchKernelGGL(cross_decode_kernel<float>, grid, dim3(256), lds, s, p);
+    else hipLaunchKernelGGL(cross_decode_kernel<bf16_t>, grid, dim3(256), lds, s, p);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
+}
+
+int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s)
+{
+    UW_REQUIRE(p.qkv && p.kcache && p.vcache && p.out && p.pos && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.n_ctx <= 512,
+               "self_attn_decode: bad arguments");
+    const dim3 grid(p.H, p.B);
+    if (dtype == UW_F32) hipLaunchKernelGGL(self_decode_kernel<float>, grid, dim3(64), 0, s, p);
+    else hipLaunchKernelGGL(self_decode_kernel<bf16_t>, grid, dim3(64), 0, s, p);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
+}
+
+int uw_greedy_advance(const GreedyState& st, const int32_t* next_tok, int B, int eot, int sot, int ts_begin, int ts_end,
+                      hipStream_t s)
+{
+    hipLaunchKernelGGL(greedy_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, next_tok, B, eot, sot, ts_begin, ts_end);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
+}

@@ -1,0 +1,131 @@
+// Internal launcher declarations shared by the .hip translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UW_F32 0
+#define UW_BF16 1
+
+static inline size_t uw_elem_size(int dtype) { return dtype == UW_F32 ? 4 : 2; }
+
+// ---- uw_gemm.hip ------------------------------------------------------------------------------
+struct GemmParams {
+    const void* A = nullptr;  // [M][K], row stride lda (elements of T)
+    const void* B = nullptr;  // [N][K], row stride ldb
+    void* C = nullptr;        // [M][N], row stride ldc (elements of TC)
+    const float* bias = nullptr;
+    const float* residual = nullptr;  // f32 [M][N], row stride ldr; may alias C
+    long lda = 0, ldb = 0, ldc = 0, ldr = 0;
+    long sA = 0, sB = 0, sC = 0, sR = 0;  // batch strides (elements)
+    int M = 0, N = 0, K = 0, batch = 1;
+    int bias_mode = 0;  // 0 none, 1 bias[n], 2 bias[m]
+    int act = 0;        // 0 none, 1 GELU(erf)
+};
+// dtype: element type of A and B.  out_f32: C is f32 even when dtype is bf16 (always f32 for UW_F32).
+int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
+
+// ---- uw_elementwise.hip -----------------------------------------------------------------------
+// y[r][:] = LayerNorm(x[r][:]) * gamma + beta, eps 1e-5.  y in dtype; y32 (optional) also gets f32.
+int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* gamma, const float* beta, long rows,
+                 int d, hipStream_t s);
+// dst (dtype) = src (f32) * scale, n elements
+int uw_convert(int dtype, const float* src, void* dst, long n, float scale, hipStream_t s);
+// conv weight [co][ci][3] f32 -> [co][kpad] dtype with k index = tap * ci_count + ci, zero padded to kpad
+int uw_pack_conv_weight(int dtype, const float* w, void* dst, int co, int ci, int kpad, hipStream_t s);
+// mel f32 [B][n_mels][3000] -> time-major zero-padded [B][3002 + slack][n_mels] dtype (row t+1 = frame t)
+int uw_mel_to_time_major(int dtype, const float* mel, void* dst, int B, int n_mels, int n_frames, long dst_stride,
+                         hipStream_t s);
+// x[b][t][:] += pos[t][:]  (f32, in place); rows = B*T
+int uw_add_positions(float* x, const float* pos, int B, int T, int d, hipStream_t s);
+// decoder input embedding: x[b][j][:] = tok_emb[ids[b*ld_ids + j]] + pos_emb[pos0[b] + j], j < T
+int uw_embed_tokens(float* x, const float* tok_emb, const float* pos_emb, const int32_t* ids, int ld_ids,
+                    const int32_t* pos0, int B, int T, int d, int vocab, int n_ctx, hipStream_t s);
+// first-max argmax over logits rows: out[b] = argmax_n logits[b][n]
+int uw_argmax_rows(const float* logits, long ld, int B, int V, int32_t* out, hipStream_t s);
+
+// ---- uw_attention.hip -------------------------------------------------------------------------
+struct AttnParams {
+    const void* Q = nullptr;   // [B][Sq][ldq], head h at column h*64, already scaled by 1/8
+    const void* K = nullptr;   // [B][Sk][ldk]
+    const void* VT = nullptr;  // [B][H*64][ldvt]  (V transposed: row = h*64 + hd, column = key)
+    void* O = nullptr;         // [B][Sq][ldo]
+    long ldq = 0, ldk = 0, ldvt = 0, ldo = 0;
+    long sQ = 0, sK = 0, sVT = 0, sO = 0;  // per-window strides (elements)
+    int B = 0, H = 0, Sq = 0, Sk = 0;
+    int causal = 0;            // query i sees keys <= i + (Sk - Sq)
+    const int32_t* sq_len = nullptr;  // optional per-window valid query count (<= Sq); rows beyond are skipped
+};
+int uw_flash_attention(int dtype, const AttnParams& p, hipStream_t s);
+
+struct ProbParams {
+    const void* Q = nullptr;  // [B][Sq][ldq]
+    const void* K = nullptr;  // [B][Sk][ldk]
+    float* P = nullptr;       // rows[b][sel][n][Sk]  (n = query index - q_first[b])
+    long ldq = 0, ldk = 0, sQ = 0, sK = 0;
+    long sP_b = 0, sP_sel = 0;  // strides of P in floats; row stride is Sk
+    int B = 0, Sq = 0, Sk = 0;
+    int n_heads_sel = 0;
+    int heads[32];              // head index of each selected head in this layer
+    int sel_slot[32];           // its slot in the [sel] axis of P
+    const int32_t* q_first = nullptr;  // per window: first query row to emit
+    const int32_t* q_count = nullptr;  // per window: number of rows to emit
+};
+int uw_attention_probs(int dtype, const ProbParams& p, hipStream_t s);
+
+// ---- uw_decode.hip ----------------------------------------------------------------------------
+struct SelfDecodeParams {
+    const void* qkv = nullptr;  // [B][3d] (q scaled | k | v) of the current token
+    void* kcache = nullptr;     // [B][n_ctx][d] for this layer
+    void* vcache = nullptr;
+    void* out = nullptr;        // [B][d]
+    const int32_t* pos = nullptr;     // per window position of the current token
+    const int32_t* active = nullptr;  // per window: 0 = finished (skip)
+    int B = 0, H = 0, d = 0, n_ctx = 0;
+};
+int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s);
+
+struct CrossDecodeParams {
+    const void* q = nullptr;   // [B][d] scaled
+    const void* K = nullptr;   // [B][S][d] for this layer
+    const void* V = nullptr;   // [B][S][d]
+    void* out = nullptr;       // [B][d]
+    float* rows = nullptr;     // attention rows [B][n_sel][n_rows_max][S] or null
+    long rows_sB = 0, rows_sSel = 0;
+    const int32_t* row_index = nullptr;  // per window: row slot to write (text tokens emitted so far)
+    const int32_t* active = nullptr;
+    int sel_slot[32];          // per head: slot in [n_sel] or -1
+    int B = 0, H = 0, d = 0, S = 0, n_rows_max = 0;
+};
+int uw_cross_attn_decode(int dtype, const CrossDecodeParams& p, hipStream_t s);
+
+struct GreedyState {
+    int32_t* tokens = nullptr;     // [B][ld_tok]  prompt + generated
+    int ld_tok = 0;
+    int32_t* pos = nullptr;        // [B] position of the token fed to the current step
+    int32_t* n_new = nullptr;      // [B] generated tokens so far
+    int32_t* n_text = nullptr;     // [B] text tokens among them (= attention row slot)
+    int32_t* active = nullptr;     // [B]
+    int32_t* dirty_from = nullptr; // [B] n_text when the first non-text token was generated, else -1
+    int32_t* max_new = nullptr;    // [B]
+    int32_t* n_active = nullptr;   // [1] windows still decoding
+    int32_t* text_ids = nullptr;   // [B][ld_tok] generated text tokens
+};
+// consumes argmax results: appends, stops on eot / budget, classifies text tokens, advances pos
+int uw_greedy_advance(const GreedyState& st, const int32_t* next_tok, int B, int eot, int sot, int ts_begin, int ts_end,
+                      hipStream_t s);
+
+// ---- uw_mel.hip -------------------------------------------------------------------------------
+struct MelTables;  // device tables owned by the context
+int uw_mel_tables_create(int n_mels, const float* filters_host /*[n_mels][201]*/, MelTables** out);
+void uw_mel_tables_destroy(MelTables* t);
+// audio [B][stride] f32 with n_samples[b] valid samples -> mel [B][n_mels][3000]
+int uw_mel_run(const MelTables* t, const float* audio, long stride, const int32_t* n_samples, int B, float* mel,
+               float* frame_max_ws /*[B]*/, hipStream_t s);
+
+// ---- uw_align.hip -----------------------------------------------------------------------------
+// rows [B][n_sel][n_rows_max][S] f32 -> cost [B][n_rows_max][S] f64 (first n_tok[b] rows written)
+int uw_cost_matrix_run(const float* rows, long sB, long sSel, int n_sel, const int32_t* n_tok, int B, int n_rows_max,
+                       int S, double* cost, hipStream_t s);
+// cost [B][n_rows_max][S] f64 -> boundaries [B][n_rows_max+1], optional path
+int uw_dtw_run(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, uint8_t* dir_ws,
+               int32_t* boundaries, int32_t* path_i, int32_t* path_j, int32_t* path_len, hipStream_t s);
