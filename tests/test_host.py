@@ -1,0 +1,45 @@
+"""Host-side logic that surrounds the GPU path (no GPU needed)."""
+import numpy as np
+
+from whisper_amd import align as A
+from whisper_amd import config as CFG
+from whisper_amd.weights import synthetic_state_dict, tensor_plan
+
+
+class FakeTokenizer:
+    sot = 50258
+    vocab = {1: " Hello", 2: " wor", 3: "ld", 4: ",", 5: " how", 6: " are", 7: " you", 8: "?"}
+
+    def decode(self, ids):
+        return "".join(self.vocab[int(i)] for i in ids)
+
+
+def test_words_from_boundaries_groups_tokens_and_keeps_punctuation_untimed():
+    ids = [1, 2, 3, 4, 5, 6, 7, 8]
+    bnd = [0, 10, 20, 30, 35, 40, 50, 60, 60]
+    words = A.words_from_boundaries(ids, bnd, FakeTokenizer(), "en")
+    assert [w["word"] for w in words] == ["Hello", "world", ",", "how", "are", "you", "?"]
+    w = {x["word"]: x for x in words}
+    assert (w["Hello"]["start"], w["Hello"]["end"]) == (0.0, 0.2)
+    assert (w["world"]["start"], w["world"]["end"]) == (0.2, 0.6)     # two tokens -> boundary[1] .. boundary[3]
+    assert w[","]["start"] is None and w["?"]["end"] is None
+    assert (w["you"]["start"], w["you"]["end"]) == (1.0, 1.2)
+
+
+def test_to_global_times_drops_context_words():
+    words = [{"word": "a", "start": 1.0, "end": 1.5}, {"word": "b", "start": 3.0, "end": 2.0}, {"word": ",", "start": None, "end": None}]
+    out = A.to_global_times(words, start_sample=160000, context_dur=2.0)
+    assert out == [{"text": "b", "start": 11.0, "end": 11.0}, {"text": ",", "start": None, "end": None}]
+
+
+def test_synthetic_weights_are_deterministic_and_complete():
+    dims = CFG.dims_for("micro")
+    a, b = synthetic_state_dict(dims, 3), synthetic_state_dict(dims, 3)
+    assert list(a) == [n for n, _, _ in tensor_plan(dims)]
+    assert all(np.array_equal(a[k].numpy(), b[k].numpy()) for k in a)
+    assert len(tensor_plan(CFG.dims_for("small"))) == 5 + 12 * 15 + 2 + 2 + 12 * 24 + 2
+
+
+def test_n_mels_rule_follows_model_string():
+    assert CFG.n_mels_for("large-v3") == 128 and CFG.n_mels_for("large-v3-turbo") == 128
+    assert CFG.n_mels_for("large") == 80 and CFG.n_mels_for("turbo") == 80 and CFG.n_mels_for("small") == 80

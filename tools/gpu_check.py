@@ -122,6 +122,10 @@ if "greedy" in stages:
         if got != ref_new:
             print("  got", got)
             print("  ref", ref_new)
+            k = next(i for i, (x, y) in enumerate(zip(got, ref_new)) if x != y)
+            lg = om.decode_full(list(pr) + ref_new[:k], enc_ref)[0, -1]
+            top = np.argsort(lg)[-3:][::-1]
+            print(f"  first mismatch at {k}: oracle top3 {top.tolist()} logits {lg[top].tolist()}")
         text = O.filter_text_tokens(ref_new, sot, ts_begin, ts_end)
         nt = int(res["n_text"][b])
         print(f"  text equal {res['text_ids'][b, :nt].cpu().tolist() == text} n_text {nt} non-text {len(ref_new) - len(text)}")

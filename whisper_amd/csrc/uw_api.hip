@@ -75,6 +75,11 @@ struct uw_ctx {
     int32_t* host_pin = nullptr;   // pinned scratch for small read-backs
     int cross_batch = 0;           // windows covered by the current cross K/V
     bool enc_valid = false;
+    // optional timing of the cross-attention decode kernel (the dominant HBM stream)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;   // start/stop pairs
+    size_t prof_used = 0;
+    long prof_launches = 0;
 };
 
 namespace {
@@ -475,7 +480,7 @@ int decoder_step(uw_ctx* c, int B, hipStream_t s)
         RUN(gemm(c, c->d_ln, d, l.self.wqkv, d, c->d_qkv, 3 * d, false, B, 3 * d, d, l.self.bqkv, 0, nullptr, 0, s));
         SelfDecodeParams sp;
         sp.qkv = c->d_qkv; sp.kcache = skv; sp.vcache = (char*)skv + (size_t)d * c->es; sp.out = c->d_attn;
-        sp.pos = c->st_pos; sp.active = c->st_active; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
+        sp.pos = c->st_pos; sp.active = c->st_active; sp.ld_cache = 2 * d; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
         RUN(uw_self_attn_decode(c->dt, sp, s));
         RUN(gemm(c, c->d_attn, d, l.self.wo, d, c->d_x, d, true, B, d, d, l.self.bo, 0, c->d_x, d, s));
         RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.cross.ln_g, l.cross.ln_b, B, d, s));
@@ -487,8 +492,12 @@ int decoder_step(uw_ctx* c, int B, hipStream_t s)
         for (int h = 0; h < 32; ++h) cp.sel_slot[h] = -1;
         for (int k = 0; k < c->n_sel; ++k)
             if (c->cfg.align_layer[k] == (int)li) cp.sel_slot[c->cfg.align_head[k]] = k;
-        cp.B = B; cp.H = H; cp.d = d; cp.S = S; cp.n_rows_max = Tm;
+        cp.B = B; cp.H = H; cp.d = d; cp.S = S; cp.n_rows_max = Tm; cp.ld_kv = 2 * d;
+        const bool timed = c->prof_on && c->prof_used + 2 <= c->prof_ev.size();
+        if (timed) UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used], s));
         RUN(uw_cross_attn_decode(c->dt, cp, s));
+        if (timed) { UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used + 1], s)); c->prof_used += 2; }
+        if (c->prof_on) ++c->prof_launches;
         RUN(gemm(c, c->d_attn, d, l.cross.wo, d, c->d_x, d, true, B, d, d, l.cross.bo, 0, c->d_x, d, s));
         RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.ln2_g, l.ln2_b, B, d, s));
         RUN(gemm(c, c->d_ln, d, l.w1, d, c->d_mlp, 4 * d, false, B, 4 * d, d, l.b1, 1, nullptr, 0, s));
@@ -636,6 +645,7 @@ int uw_ctx_destroy(uw_ctx* c)
     if (!c) return UW_OK;
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
+    for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
     if (c->host_pin) (void)hipHostFree(c->host_pin);
     uw_mel_tables_destroy(c->mel_tables);
     delete c;
@@ -643,6 +653,37 @@ int uw_ctx_destroy(uw_ctx* c)
 }
 
 int64_t uw_ctx_bytes(const uw_ctx* c) { return c ? c->bytes : 0; }
+
+int uw_profile_begin(uw_ctx* c, int max_launches)
+{
+    UW_REQUIRE(c && max_launches > 0 && max_launches <= (1 << 20), "uw_profile_begin: bad arguments");
+    while (c->prof_ev.size() < (size_t)2 * max_launches) {
+        hipEvent_t e;
+        UW_HIP_CHECK(hipEventCreate(&e));
+        c->prof_ev.push_back(e);
+    }
+    c->prof_used = 0;
+    c->prof_launches = 0;
+    c->prof_on = true;
+    return UW_OK;
+}
+
+int uw_profile_end(uw_ctx* c, int64_t* launches_total, int64_t* launches_timed, double* timed_ms)
+{
+    UW_REQUIRE(c && c->prof_on, "uw_profile_end: profiling was not started");
+    c->prof_on = false;
+    UW_HIP_CHECK(hipDeviceSynchronize());
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+        float t = 0.f;
+        UW_HIP_CHECK(hipEventElapsedTime(&t, c->prof_ev[i], c->prof_ev[i + 1]));
+        ms += t;
+    }
+    if (launches_total) *launches_total = c->prof_launches;
+    if (launches_timed) *launches_timed = (int64_t)(c->prof_used / 2);
+    if (timed_ms) *timed_ms = ms;
+    return UW_OK;
+}
 
 int uw_mel(uw_ctx* c, const float* audio, int64_t stride, const int32_t* n_samples, int B, float* mel_out, void* stream)
 {

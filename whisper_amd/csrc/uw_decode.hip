@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
     if (p.active && !p.active[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane % R::LPR, rin = lane / R::LPR;
-    const long ld = p.d;
+    const long ld = p.ld_kv;
     const T* Kh = (const T*)p.K + (long)b * S * ld + h * 64 + sub * R::E;
     const T* Vh = (const T*)p.V + (long)b * S * ld + h * 64 + sub * R::E;
 
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void self_decode_kernel(SelfDecodeParams p)
     const int pos = p.pos[b];
     if (pos < 0 || pos >= p.n_ctx || pos >= 512) return;
     const int sub = lane % R::LPR, rin = lane / R::LPR;
-    const long ld = p.d;
+    const long ld = p.ld_cache;
     const T* qkv = (const T*)p.qkv + (long)b * 3 * p.d + h * 64 + sub * R::E;
     T* Kc = (T*)p.kcache + (long)b * p.n_ctx * ld + h * 64 + sub * R::E;
     T* Vc = (T*)p.vcache + (long)b * p.n_ctx * ld + h * 64 + sub * R::E;
@@ -264,7 +264,7 @@ __global__ void greedy_advance_kernel(GreedyState st, const int32_t* __restrict_
 
 int uw_cross_attn_decode(int dtype, const CrossDecodeParams& p, hipStream_t s)
 {
-    UW_REQUIRE(p.q && p.K && p.V && p.out && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.S > 0 && p.S <= 4096,
+    UW_REQUIRE(p.q && p.K && p.V && p.out && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.S > 0 && p.S <= 4096 && p.ld_kv >= p.d,
                "cross_attn_decode: bad arguments");
     UW_REQUIRE(!p.rows || p.row_index, "cross_attn_decode: rows without row_index");
     const size_t lds = (size_t)(((p.S + 63) & ~63) + 8 + 256) * 4;
@@ -277,7 +277,7 @@ int uw_cross_attn_decode(int dtype, const CrossDecodeParams& p, hipStream_t s)
 
 int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s)
 {
-    UW_REQUIRE(p.qkv && p.kcache && p.vcache && p.out && p.pos && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.n_ctx <= 512,
+    UW_REQUIRE(p.qkv && p.kcache && p.vcache && p.out && p.pos && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.n_ctx <= 512 && p.ld_cache >= p.d,
                "self_attn_decode: bad arguments");
     const dim3 grid(p.H, p.B);
     if (dtype == UW_F32) hipLaunchKernelGGL(self_decode_kernel<float>, grid, dim3(64), 0, s, p);

@@ -80,6 +80,7 @@ struct SelfDecodeParams {
     void* out = nullptr;        // [B][d]
     const int32_t* pos = nullptr;     // per window position of the current token
     const int32_t* active = nullptr;  // per window: 0 = finished (skip)
+    long ld_cache = 0;          // row stride of the caches (elements); 2*d when K and V rows are interleaved
     int B = 0, H = 0, d = 0, n_ctx = 0;
 };
 int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s);
@@ -94,6 +95,7 @@ struct CrossDecodeParams {
     const int32_t* row_index = nullptr;  // per window: row slot to write (text tokens emitted so far)
     const int32_t* active = nullptr;
     int sel_slot[32];          // per head: slot in [n_sel] or -1
+    long ld_kv = 0;            // row stride of K and V (elements)
     int B = 0, H = 0, d = 0, S = 0, n_rows_max = 0;
 };
 int uw_cross_attn_decode(int dtype, const CrossDecodeParams& p, hipStream_t s);

@@ -79,6 +79,14 @@ class Engine:
     def _s(self) -> int:
         return L.stream_handle()
 
+    def profile_begin(self, max_launches: int = 16384) -> None:
+        L.check(self.lib.uw_profile_begin(self.ctx, int(max_launches)))
+
+    def profile_end(self) -> Dict[str, float]:
+        total, timed, ms = C.c_int64(), C.c_int64(), C.c_double()
+        L.check(self.lib.uw_profile_end(self.ctx, C.byref(total), C.byref(timed), C.byref(ms)))
+        return {"launches": total.value, "timed": timed.value, "timed_ms": ms.value}
+
     # ---- stages ---------------------------------------------------------------------------------
     def mel(self, audio: torch.Tensor, n_samples: torch.Tensor) -> torch.Tensor:
         """audio f32 [B, stride] (cuda), n_samples i32 [B] -> log-mel f32 [B, n_mels, 3000]."""
