@@ -60,7 +60,7 @@ def test_cost_matrix_ragged_batch_and_median_edges():
     for b in range(B):
         n = int(n_tok[b])
         ref = O.cost_matrix([rows[b, k, :n][None, None] for k in range(n_sel)], [(k, 0) for k in range(n_sel)])
-        assert np.allclose(cost[b, :n], ref, rtol=3e-6, atol=0)
+        assert np.allclose(cost[b, :n], ref, rtol=3e-5, atol=1e-30)   # exp() of arguments down to -50: |x| * eps
         assert np.all(cost[b, n:] == 0)    # rows past n_tok are not touched
 
 
