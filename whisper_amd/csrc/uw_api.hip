@@ -305,6 +305,8 @@ int gemm(uw_ctx* c, const void* A, long lda, const void* Bw, long ldb, void* C, 
     p.M = M; p.N = N; p.K = K; p.batch = batch;
     p.bias_mode = bias ? bias_mode : 0;
     p.act = act;
+    // decode-step shapes: few rows, modest N -> stream the weights once over many small workgroups
+    if (batch == 1 && M <= 128 && N <= 8192) return uw_gemm_skinny(c->dt, out_f32 ? 1 : 0, p, s);
     return uw_gemm(c->dt, out_f32 ? 1 : 0, p, s);
 }
 

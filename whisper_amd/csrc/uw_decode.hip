@@ -159,13 +159,16 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// causal self-attention for one new token: grid (H, B), one wave; also appends this token's K/V to the cache
+// causal self-attention for one new token: grid (H, B), 256 threads; also appends this token's K/V to the cache.
+// Same structure as the cross kernel over the pos+1 cached rows; the row being appended is taken from registers.
 template <typename T>
-__global__ __launch_bounds__(64) void self_decode_kernel(SelfDecodeParams p)
+__global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
 {
     using R = Row<T>;
     __shared__ float sc[512];
-    const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    __shared__ float red[8];
+    __shared__ float part[4 * 64];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (p.active && !p.active[b]) return;
     const int pos = p.pos[b];
     if (pos < 0 || pos >= p.n_ctx || pos >= 512) return;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(64) void self_decode_kernel(SelfDecodeParams p)
     T* Kc = (T*)p.kcache + (long)b * p.n_ctx * ld + h * 64 + sub * R::E;
     T* Vc = (T*)p.vcache + (long)b * p.n_ctx * ld + h * 64 + sub * R::E;
     const uint4 knew = *(const uint4*)(qkv + p.d), vnew = *(const uint4*)(qkv + 2 * p.d);
-    if (rin == 0) {
+    if (wave == 0 && rin == 0) {
         *(uint4*)(Kc + (long)pos * ld) = knew;
         *(uint4*)(Vc + (long)pos * ld) = vnew;
     }
@@ -183,37 +186,60 @@ __global__ __launch_bounds__(64) void self_decode_kernel(SelfDecodeParams p)
 #pragma unroll
     for (int e = 0; e < R::E; ++e) q[e] = to_f32<T>(qkv[e]);
     const int n = pos + 1;
-    for (int r0 = 0; r0 < n; r0 += R::RPI) {
-        const int r = r0 + rin;
-        uint4 kv = knew;
-        if (r < pos) kv = *(const uint4*)(Kc + (long)r * ld);
-        const float s = row_sum<T>(dot_chunk<T>(kv, q));
-        if (sub == 0 && r < n) sc[r] = s;
+    constexpr int U = 4;
+    const int rows_per_round = 4 * R::RPI * U;
+    for (int r0 = 0; r0 < n; r0 += rows_per_round) {
+        uint4 kv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            kv[u] = knew;
+            if (r < pos) kv[u] = *(const uint4*)(Kc + (long)r * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            const float s = row_sum<T>(dot_chunk<T>(kv[u], q));
+            if (sub == 0 && r < n) sc[r] = s;
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
-    for (int j = lane; j < n; j += 64) mx = fmaxf(mx, sc[j]);
+    for (int j = tid; j < n; j += 256) mx = fmaxf(mx, sc[j]);
     mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float sum = 0.f;
-    for (int j = lane; j < n; j += 64) {
+    for (int j = tid; j < n; j += 256) {
         const float e = __expf(sc[j] - mx);
         sc[j] = e;
         sum += e;
     }
-    const float inv = 1.0f / wave_sum(sum);
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
     __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
     float acc[R::E];
 #pragma unroll
     for (int e = 0; e < R::E; ++e) acc[e] = 0.f;
-    for (int r0 = 0; r0 < n; r0 += R::RPI) {
-        const int r = r0 + rin;
-        uint4 vv = vnew;
-        if (r < pos) vv = *(const uint4*)(Vc + (long)r * ld);
-        const float w = (r < n) ? sc[r] * inv : 0.f;
-        float f[R::E];
-        unpack<T>(vv, f);
+    for (int r0 = 0; r0 < n; r0 += rows_per_round) {
+        uint4 vv[U];
 #pragma unroll
-        for (int e = 0; e < R::E; ++e) acc[e] = fmaf(w, f[e], acc[e]);
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            vv[u] = vnew;
+            if (r < pos) vv[u] = *(const uint4*)(Vc + (long)r * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            const float w = (r < n) ? sc[r] * inv : 0.f;
+            float f[R::E];
+            unpack<T>(vv[u], f);
+#pragma unroll
+            for (int e = 0; e < R::E; ++e) acc[e] = fmaf(w, f[e], acc[e]);
+        }
     }
 #pragma unroll
     for (int e = 0; e < R::E; ++e) {
@@ -221,9 +247,13 @@ __global__ __launch_bounds__(64) void self_decode_kernel(SelfDecodeParams p)
         for (int o = R::LPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
     }
     if (rin == 0) {
-        T* o = (T*)p.out + (long)b * p.d + h * 64 + sub * R::E;
 #pragma unroll
-        for (int e = 0; e < R::E; ++e) o[e] = from_f32<T>(acc[e]);
+        for (int e = 0; e < R::E; ++e) part[wave * 64 + sub * R::E + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float o = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+        ((T*)p.out)[(long)b * p.d + h * 64 + tid] = from_f32<T>(o);
     }
 }
 
@@ -280,8 +310,8 @@ int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s)
     UW_REQUIRE(p.qkv && p.kcache && p.vcache && p.out && p.pos && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.n_ctx <= 512 && p.ld_cache >= p.d,
                "self_attn_decode: bad arguments");
     const dim3 grid(p.H, p.B);
-    if (dtype == UW_F32) hipLaunchKernelGGL(self_decode_kernel<float>, grid, dim3(64), 0, s, p);
-    else hipLaunchKernelGGL(self_decode_kernel<bf16_t>, grid, dim3(64), 0, s, p);
+    if (dtype == UW_F32) hipLaunchKernelGGL(self_decode_kernel<float>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(self_decode_kernel<bf16_t>, grid, dim3(256), 0, s, p);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }

@@ -132,19 +132,32 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(float* __restrict__ x
     for (int c = threadIdx.x; c < (d >> 2); c += 256) o[c] = e[c] + p[c];
 }
 
-// first index of the maximum (numpy argmax tie rule); NaN never wins here, inputs are finite logits
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, long ld, int V,
-                                                          int32_t* __restrict__ out)
+// first index of the maximum (numpy argmax tie rule); NaN never wins here, inputs are finite logits.
+// One 1024-thread workgroup per row, 16-byte loads, four independent loads in flight per thread.
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restrict__ logits, long ld, int V,
+                                                           int32_t* __restrict__ out)
 {
-    __shared__ float sv[4];
-    __shared__ int si[4];
+    __shared__ float sv[16];
+    __shared__ int si[16];
     const float* row = logits + (long)blockIdx.x * ld;
     float best = -INFINITY;
     int arg = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += 256) {
-        const float v = row[i];
-        if (v > best) { best = v; arg = i; }   // ascending i per thread: '>' keeps the first
+    auto take = [&](float v, int i) { if (v > best || (v == best && i < arg)) { best = v; arg = i; } };
+    const bool vec = ((ld & 3) == 0) && (((uintptr_t)logits & 15) == 0);
+    const int V4 = vec ? (V >> 2) : 0;
+    for (int i0 = threadIdx.x; i0 < V4; i0 += 4096) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024;
+            v[u] = (i < V4) ? ((const f32x4*)row)[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) take(v[u][k], (i0 + u * 1024) * 4 + k);
     }
+    for (int i = V4 * 4 + threadIdx.x; i < V; i += 1024) take(row[i], i);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float ov = __shfl_xor(best, o, 64);
@@ -154,7 +167,7 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = arg; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < 16; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < arg)) { best = sv[w]; arg = si[w]; }
         out[blockIdx.x] = (arg == 0x7fffffff) ? 0 : arg;
     }
@@ -225,7 +238,7 @@ int uw_embed_tokens(float* x, const float* tok_emb, const float* pos_emb, const 
 
 int uw_argmax_rows(const float* logits, long ld, int B, int V, int32_t* out, hipStream_t s)
 {
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(256), 0, s, logits, ld, V, out);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(B), dim3(1024), 0, s, logits, ld, V, out);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }

@@ -147,7 +147,149 @@ template <typename T, typename TC> int launch(const GemmParams& p, hipStream_t s
     return UW_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Skinny form for the decode step (M = windows in flight <= 128): the weight matrix is streamed exactly
+// once, 16 output columns per workgroup so that even N = d_model gives dozens of workgroups.  The step is
+// latency-bound, not bandwidth-bound, so the 8 waves of a workgroup split K and every wave issues the
+// loads of a whole round of three 32-deep K-steps (27 x 16 B per lane) before its first MFMA; partial tiles
+// are combined through LDS in a fixed order (results are run-to-run identical).  Activations (<= 128 rows)
+// stay L2-resident and are read as MFMA fragments straight from global memory.
+constexpr int SK_WAVES = 8;
+constexpr int SK_ROUND = 3;   // K-steps whose loads are in flight together
+
+template <typename T, typename TC, int MT>
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = 16 / (int)sizeof(T);
+    constexpr int KS = 4 * E;                 // K elements per step (one MFMA chunk group)
+    f32x4* part = (f32x4*)smem;               // [SK_WAVES][MT][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: K offsets stay scalar
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int steps_total = p.K / KS;
+    const int s_begin = (steps_total * wave) / SK_WAVES, s_end = (steps_total * (wave + 1)) / SK_WAVES;
+    // buffer descriptors keep the loads in the global address space with 32-bit per-lane offsets; the K
+    // position of a round is a scalar offset and the step inside the round an immediate
+    constexpr int ES = (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((long)p.N * p.ldb * ES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((long)p.M * p.lda * ES), 0x00020000);
+    const int woff = (int)(((long)min(n0 + fr, p.N - 1) * p.ldb + fg * E) * ES);
+    int aoff[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) aoff[mt] = (int)(((long)min(mt * 16 + fr, p.M - 1) * p.lda + fg * E) * ES);
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto ld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) -> uint4 {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    int s = s_begin;
+    for (; s + SK_ROUND <= s_end; s += SK_ROUND) {      // full rounds: every load issued before the first MFMA
+        const int koff = s * KS * ES;
+        uint4 wv[SK_ROUND], av[SK_ROUND][MT];
+#pragma unroll
+        for (int r = 0; r < SK_ROUND; ++r) {
+            wv[r] = ld(rsW, woff + r * KS * ES, koff);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[r][mt] = ld(rsA, aoff[mt] + r * KS * ES, koff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < SK_ROUND; ++r)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) mma16<T>(wv[r], av[r][mt], acc[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; s < s_end; ++s) {                            // leftover steps
+        const int koff = s * KS * ES;
+        const uint4 wv = ld(rsW, woff, koff);
+        uint4 av[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) av[mt] = ld(rsA, aoff[mt], koff);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) mma16<T>(wv, av[mt], acc[mt]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) part[(wave * MT + mt) * 64 + lane] = acc[mt];
+    __syncthreads();
+    // wave w < MT finishes row tile w
+    const int mt = wave;
+    const int m = mt * 16 + fr, n = n0 + fg * 4;
+    if (mt >= MT || m >= p.M || n >= p.N) return;
+    f32x4 t = part[mt * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < SK_WAVES; ++w) t += part[(w * MT + mt) * 64 + lane];
+    TC* __restrict__ C = (TC*)p.C;
+    const float* __restrict__ R = p.residual;
+    const bool vec_ok = ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0) && (n + 3 < p.N);
+    float v[4] = {t[0], t[1], t[2], t[3]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (p.bias_mode == 1) v[r] += (n + r < p.N) ? p.bias[n + r] : 0.f;
+        else if (p.bias_mode == 2) v[r] += p.bias[m];
+        if (p.act == 1) v[r] = gelu_erf(v[r]);
+    }
+    if (vec_ok) {
+        if (R) {
+            const f32x4 rv = *(const f32x4*)(R + (long)m * p.ldr + n);
+            v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+        }
+        if constexpr (sizeof(TC) == 4) {
+            *(f32x4*)((float*)C + (long)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+            union { bf16_t h[4]; uint2 u; } pk;
+            pk.h[0] = (bf16_t)v[0]; pk.h[1] = (bf16_t)v[1]; pk.h[2] = (bf16_t)v[2]; pk.h[3] = (bf16_t)v[3];
+            *(uint2*)((bf16_t*)C + (long)m * p.ldc + n) = pk.u;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= p.N) break;
+            float x = v[r];
+            if (R) x += R[(long)m * p.ldr + n + r];
+            C[(long)m * p.ldc + n + r] = from_f32<TC>(x);
+        }
+    }
+}
+
+template <typename T, typename TC, int MT> int launch_skinny_mt(const GemmParams& p, hipStream_t s)
+{
+    const size_t lds = (size_t)SK_WAVES * MT * 64 * sizeof(f32x4);
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT>), dim3((p.N + 15) / 16), dim3(64 * SK_WAVES), lds, s, p);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
+}
+
+template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStream_t s)
+{
+    constexpr int KS = 64 / (int)sizeof(T);
+    UW_REQUIRE(p.M > 0 && p.M <= 128 && p.N > 0 && p.K > 0 && p.batch == 1, "skinny gemm: M=%d outside 1..128", p.M);
+    UW_REQUIRE(p.K % KS == 0, "skinny gemm: K=%d must be a multiple of %d", p.K, KS);
+    UW_REQUIRE((p.lda * sizeof(T)) % 16 == 0 && (p.ldb * sizeof(T)) % 16 == 0 && ((uintptr_t)p.A % 16) == 0 &&
+                   ((uintptr_t)p.B % 16) == 0,
+               "skinny gemm: operand rows must be 16-byte aligned");
+    UW_REQUIRE((long)p.N * p.ldb * (long)sizeof(T) < (1l << 31) && (long)p.M * p.lda * (long)sizeof(T) < (1l << 31),
+               "skinny gemm: operands must be under 2 GiB");
+    if (p.M <= 16) return launch_skinny_mt<T, TC, 1>(p, s);
+    if (p.M <= 32) return launch_skinny_mt<T, TC, 2>(p, s);
+    if (p.M <= 64) return launch_skinny_mt<T, TC, 4>(p, s);
+    return launch_skinny_mt<T, TC, 8>(p, s);
+}
+
 }  // namespace
+
+int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
+{
+    if (dtype == UW_F32) return launch_skinny<float, float>(p, s);
+    if (out_f32) return launch_skinny<bf16_t, float>(p, s);
+    return launch_skinny<bf16_t, bf16_t>(p, s);
+}
 
 int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
 {

@@ -23,6 +23,8 @@ struct GemmParams {
 };
 // dtype: element type of A and B.  out_f32: C is f32 even when dtype is bf16 (always f32 for UW_F32).
 int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
+// M <= 128, batch 1: weight-streaming form for the decode step
+int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
 
 // ---- uw_elementwise.hip -----------------------------------------------------------------------
 // y[r][:] = LayerNorm(x[r][:]) * gamma + beta, eps 1e-5.  y in dtype; y32 (optional) also gets f32.
