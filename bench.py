@@ -169,8 +169,10 @@ def main():
     audio_seconds = 30.0 * B * world * args.steps
     value = audio_seconds / elapsed
     es = 2 if args.dtype == "bf16" else 4
-    # algorithmic bytes of ONE cross-attention decode launch: K and V of one decoder layer for every window
-    bytes_per_launch = B * 2 * 1500 * dims.d_model * es
+    # algorithmic bytes of ONE cross-attention decode launch: K and V of one decoder layer for the windows it
+    # covers (the decode loop runs disjoint window ranges on separate streams, so a launch covers B / n_streams)
+    windows_per_launch = prof["windows"] / max(1, prof["launches"])
+    bytes_per_launch = windows_per_launch * 2 * 1500 * dims.d_model * es
     avg_ms = prof["timed_ms"] / max(1, prof["timed"])
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     line = {
@@ -184,7 +186,7 @@ def main():
                    "global_batch": B * world, "prompt_len": P, "generated_per_window": float(n_new.mean()),
                    "text_tokens_per_window": float(n_text.mean()), "parallelism": f"dp{world} (independent windows)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "kernel": "cross_decode_kernel", "bytes_per_launch": bytes_per_launch,
+                     "traffic": None, "kernel": "cross_decode_kernel", "bytes_per_launch": bytes_per_launch, "windows_per_launch": windows_per_launch,
                      "avg_launch_ms": avg_ms, "launches_timed": prof["timed"], "launches": prof["launches"]},
     }
     if rank == 0:

@@ -116,9 +116,11 @@ int uw_transcribe_windows(uw_ctx* ctx, const float* audio, int64_t stride, const
 /* Measurement aid (no reference counterpart): brackets every launch of the cross-attention decode kernel --
  * the kernel that streams the cross K/V cache and bounds the path -- with HIP events on the caller's stream.
  * uw_profile_end synchronises the device and returns how many launches ran, how many were timed (the event
- * pool holds max_launches pairs) and the summed duration of the timed ones. */
+ * pool holds max_launches pairs), how many windows those launches covered in total (a launch streams the K/V
+ * of one decoder layer for its windows) and the summed duration of the timed ones. */
 int uw_profile_begin(uw_ctx* ctx, int max_launches);
-int uw_profile_end(uw_ctx* ctx, int64_t* launches_total, int64_t* launches_timed, double* timed_ms);
+int uw_profile_end(uw_ctx* ctx, int64_t* launches_total, int64_t* launches_timed, int64_t* windows_total,
+                   double* timed_ms);
 
 #ifdef __cplusplus
 }

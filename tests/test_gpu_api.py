@@ -1,0 +1,126 @@
+"""GPU tests of the drop-in boundary: ORT-shaped sessions and whisperer() on top of the HIP engine."""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import whisper_oracle as O
+from tests.helpers import synth_audio
+from whisper_amd import whisperer
+from whisper_amd.config import dims_for
+from whisper_amd.model import load_onnx_models
+from whisper_amd.weights import synthetic_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+class MicroTokenizer:
+    """Whisper-tokenizer-shaped stand-in for the 1024-entry micro vocabulary: id t < 800 decodes to ' w<t>',
+    ids 800..822 to punctuation, specials as in the real layout (eot < sot < ... < timestamps)."""
+    eot, sot, sot_prev, no_timestamps, timestamp_begin = 823, 824, 827, 828, 924
+    transcribe, translate, task = 826, 829, 826
+    language = "en"
+
+    def decode(self, ids):
+        out = []
+        for t in ids:
+            t = int(t)
+            if t < 800:
+                out.append(f" w{t}")
+            elif t < 823:
+                out.append(",")
+        return "".join(out)
+
+    def encode(self, text, allowed_special=None):
+        specials = {"<|en|>": 825, "<|transcribe|>": 826, "<|30.00|>": 924 + 99}
+        if text in specials:
+            return [specials[text]]
+        ids = []
+        for m in re.finditer(r"w(\d+)|,|-", text):
+            ids.append(int(m.group(1)) if m.group(1) else (801 if m.group(0) == "," else 802))
+        return ids
+
+
+@pytest.fixture(scope="module")
+def sessions():
+    enc, dec = load_onnx_models("synthetic:micro", None, onnx_providers=["MI355XExecutionProvider"], dtype="f32", max_batch=2)
+    yield enc, dec
+    enc.engine.close()
+
+
+def test_sessions_look_like_onnxruntime(sessions):
+    enc, dec = sessions
+    assert enc.get_providers() == ["MI355XExecutionProvider"]
+    assert [i.name for i in dec.get_inputs()] == ["input_ids", "encoder_hidden_states"]
+    names = [o.name for o in dec.get_outputs()]
+    assert names[0] == "logits" and [n for n in names if "cross_attentions" in n] == ["cross_attentions.0", "cross_attentions.1"]
+    with pytest.raises(Exception, match="are missing from input feed"):
+        dec.run(["logits"], {"input_ids": np.zeros((1, 2), np.int64)})
+    with pytest.raises(RuntimeError):
+        load_onnx_models("synthetic:micro", None, onnx_providers=["CUDAExecutionProvider"])
+
+
+def test_sessions_reproduce_reference_loops(sessions):
+    """Drive the sessions exactly as core.py:824-830, 941-968 and align.py:608-618 do."""
+    enc, dec = sessions
+    dims = dims_for("micro")
+    om = O.OracleModel(synthetic_state_dict(dims, 0), dims.n_heads)
+    mel = O.log_mel_segment(synth_audio(4), 80)
+    hidden = enc.run(None, {enc.get_inputs()[0].name: mel.astype(np.float32)})[0]
+    assert hidden.shape == (1, 1500, dims.d_model)
+    assert np.abs(hidden - om.encode(mel)).max() < 1e-4
+    cur = [824, 825, 826, 924]
+    for _ in range(5):
+        logits = dec.run(["logits"], {"input_ids": np.array([cur], dtype=np.int64), "encoder_hidden_states": hidden.astype(np.float32)})[0]
+        ref = om.decode_full(cur, hidden)
+        assert logits.shape == ref.shape and np.abs(logits - ref).max() < 1e-4
+        cur.append(int(np.argmax(logits[0, -1, :])))
+    attn_names = [o.name for o in dec.get_outputs() if "cross_attentions" in o.name]
+    outs = dec.run(attn_names, {"input_ids": np.array([cur], dtype=np.int64), "encoder_hidden_states": hidden.astype(np.float32)})
+    _, cross = om.decode_full(cur, hidden, want_attn=True)
+    for got, ref in zip(outs, cross):
+        assert got.shape == (1, dims.n_heads, len(cur), 1500) and np.abs(got - ref).max() < 1e-6
+
+
+def _engine(max_batch=4):
+    from whisper_amd.engine import Engine
+    dims = dims_for("micro")
+    return Engine(dims, synthetic_state_dict(dims, 0, std=0.06), dtype="f32", max_batch=max_batch, align_heads=[(0, 1), (1, 0), (1, 1)])
+
+
+def test_whisperer_result_contract_and_batched_chunks():
+    eng = _engine()
+    audio = np.concatenate([synth_audio(7), synth_audio(8, 200000)])       # 42.5 s -> two chunks
+    res = whisperer("synthetic:micro", audio, language="en", max_tokens=24, tokenizer=MicroTokenizer(), engine=eng)
+    assert set(res) == {"text", "words", "tokens", "language"} and res["language"] == "en"
+    assert len(res["tokens"]) == 2 * 20 and all(isinstance(t, int) for t in res["tokens"])
+    assert res["text"] and all(set(w) == {"text", "start", "end"} for w in res["words"])
+    starts = [w["start"] for w in res["words"]]
+    # DTW always spans the 1500 encoder frames, so stamps of the short second chunk run up to 30 s + 30 s (as in the reference)
+    assert all(0.0 <= s <= 60.0 for s in starts) and any(s >= 30.0 for s in starts)
+    assert all(w["end"] >= w["start"] for w in res["words"])
+    # chunks are independent without a delimiter: transcribing the first 30 s alone gives the same first 20 tokens
+    first = whisperer("synthetic:micro", audio[:480000], max_tokens=24, tokenizer=MicroTokenizer(), engine=eng)
+    assert first["tokens"] == res["tokens"][:20]
+    with pytest.raises(TypeError):
+        whisperer("synthetic:micro", [1, 2, 3], tokenizer=MicroTokenizer(), engine=eng)
+    with pytest.raises(ValueError):
+        whisperer("synthetic:micro", audio, transcript="w1 w2", stream=True, tokenizer=MicroTokenizer(), engine=eng)
+    eng.close()
+
+
+def test_whisperer_delimiter_stream_and_transcript_modes():
+    eng = _engine()
+    tok = MicroTokenizer()
+    audio = np.concatenate([synth_audio(9), synth_audio(10, 100000)])
+    res = whisperer("synthetic:micro", audio, delimiter=" -", max_tokens=30, tokenizer=tok, engine=eng)
+    assert len(res["tokens"]) > 0 and isinstance(res["text"], str)
+    pieces = list(whisperer("synthetic:micro", audio[:480000], stream=True, max_tokens=16, tokenizer=tok, engine=eng))
+    assert pieces and all(p.startswith(" w") or p == "," for p in pieces)
+    transcript = " ".join(f"w{i}" for i in range(5, 45))
+    al = whisperer("synthetic:micro", audio, transcript=transcript, tokenizer=tok, engine=eng)
+    assert al["text"] == transcript and al["tokens"] == list(range(5, 45))
+    assert al["words"] and all(w["start"] is not None and 0 <= w["start"] <= len(audio) / 16000 + 30 for w in al["words"])
+    assert [w["start"] for w in al["words"]] == sorted(w["start"] for w in al["words"])
+    eng.close()

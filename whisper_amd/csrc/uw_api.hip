@@ -3,6 +3,8 @@
 #include "uw_common.h"
 #include "uw_kernels.h"
 #include <stdarg.h>
+#include <stdlib.h>
+#include <algorithm>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -80,6 +82,13 @@ struct uw_ctx {
     std::vector<hipEvent_t> prof_ev;   // start/stop pairs
     size_t prof_used = 0;
     long prof_launches = 0;
+    long prof_windows = 0;             // windows summed over the launches
+    // side streams: disjoint window ranges decode concurrently so one range's latency-bound small kernels
+    // overlap another range's bandwidth-bound cross-attention stream
+    hipStream_t sub_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t sub_event[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork_event = nullptr;
+    int n_streams = 4;
 };
 
 namespace {
@@ -246,6 +255,20 @@ int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
     RUN(copy_f32(c->dec_ln_g, dlg, d, 1.f));
     RUN(copy_f32(c->dec_ln_b, dlb, d, 1.f));
     UW_HIP_CHECK(hipDeviceSynchronize());
+    return UW_OK;
+}
+
+int create_streams(uw_ctx* c)
+{
+    const char* env = getenv("UW_DECODE_STREAMS");
+    c->n_streams = env ? atoi(env) : 1;   // concurrent queues did not overlap on MI355X (measured): one stream by default
+    if (c->n_streams < 1) c->n_streams = 1;
+    if (c->n_streams > 4) c->n_streams = 4;
+    for (int k = 0; k < 4; ++k) {
+        UW_HIP_CHECK(hipStreamCreateWithFlags(&c->sub_stream[k], hipStreamNonBlocking));
+        UW_HIP_CHECK(hipEventCreateWithFlags(&c->sub_event[k], hipEventDisableTiming));
+    }
+    UW_HIP_CHECK(hipEventCreateWithFlags(&c->fork_event, hipEventDisableTiming));
     return UW_OK;
 }
 
@@ -468,29 +491,40 @@ __global__ void embed_step_kernel(float* __restrict__ x, const float* __restrict
     for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) o[i] = e[i] + pe[i];
 }
 
-// one KV-cached decoder step for the token at st_pos[b] of every active window -> c->logits
-int decoder_step(uw_ctx* c, int B, hipStream_t s)
+// one KV-cached decoder step for the token at st_pos[b] of windows [b0, b0 + B) -> their rows of c->logits.
+// Every buffer is indexed by window, so disjoint window ranges can run on different streams concurrently.
+int decoder_step(uw_ctx* c, int b0, int B, hipStream_t s)
 {
     const int d = c->d, S = c->S, H = c->H, Tm = c->Tm;
-    hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, s, c->d_x, c->tok_emb32, c->dec_pos, c->st_tokens, Tm, c->st_pos, d, c->V, Tm);
+    const size_t es = c->es;
+    float* x = c->d_x + (long)b0 * d;
+    char* ln = (char*)c->d_ln + (size_t)b0 * d * es;
+    char* qkv = (char*)c->d_qkv + (size_t)b0 * 3 * d * es;
+    char* att = (char*)c->d_attn + (size_t)b0 * d * es;
+    char* mlp = (char*)c->d_mlp + (size_t)b0 * 4 * d * es;
+    float* logits = c->logits + (long)b0 * c->logits_ld;
+    const int32_t* pos = c->st_pos + b0;
+    const int32_t* active = c->st_active + b0;
+    hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, s, x, c->tok_emb32, c->dec_pos, c->st_tokens + (long)b0 * Tm, Tm, pos, d, c->V, Tm);
     UW_LAUNCH_CHECK();
     for (size_t li = 0; li < c->dec.size(); ++li) {
         auto& l = c->dec[li];
-        void* skv = (char*)c->self_kv + li * self_kv_layer_bytes(c);
-        void* ckv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c);
-        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.self.ln_g, l.self.ln_b, B, d, s));
-        RUN(gemm(c, c->d_ln, d, l.self.wqkv, d, c->d_qkv, 3 * d, false, B, 3 * d, d, l.self.bqkv, 0, nullptr, 0, s));
+        char* skv = (char*)c->self_kv + li * self_kv_layer_bytes(c) + (size_t)b0 * Tm * 2 * d * es;
+        char* ckv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c) + (size_t)b0 * S * 2 * d * es;
+        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.self.ln_g, l.self.ln_b, B, d, s));
+        RUN(gemm(c, ln, d, l.self.wqkv, d, qkv, 3 * d, false, B, 3 * d, d, l.self.bqkv, 0, nullptr, 0, s));
         SelfDecodeParams sp;
-        sp.qkv = c->d_qkv; sp.kcache = skv; sp.vcache = (char*)skv + (size_t)d * c->es; sp.out = c->d_attn;
-        sp.pos = c->st_pos; sp.active = c->st_active; sp.ld_cache = 2 * d; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
+        sp.qkv = qkv; sp.kcache = skv; sp.vcache = skv + (size_t)d * es; sp.out = att;
+        sp.pos = pos; sp.active = active; sp.ld_cache = 2 * d; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
         RUN(uw_self_attn_decode(c->dt, sp, s));
-        RUN(gemm(c, c->d_attn, d, l.self.wo, d, c->d_x, d, true, B, d, d, l.self.bo, 0, c->d_x, d, s));
-        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.cross.ln_g, l.cross.ln_b, B, d, s));
-        RUN(gemm(c, c->d_ln, d, l.cross.wq, d, c->d_qkv, d, false, B, d, d, l.cross.bq, 0, nullptr, 0, s));
+        RUN(gemm(c, att, d, l.self.wo, d, x, d, true, B, d, d, l.self.bo, 0, x, d, s));
+        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.cross.ln_g, l.cross.ln_b, B, d, s));
+        RUN(gemm(c, ln, d, l.cross.wq, d, qkv, d, false, B, d, d, l.cross.bq, 0, nullptr, 0, s));
         CrossDecodeParams cp;
-        cp.q = c->d_qkv; cp.K = ckv; cp.V = (char*)ckv + (size_t)d * c->es; cp.out = c->d_attn;
-        cp.rows = c->rows; cp.rows_sB = (long)c->n_sel * Tm * S; cp.rows_sSel = (long)Tm * S;
-        cp.row_index = c->st_n_text; cp.active = c->st_active;
+        cp.q = qkv; cp.K = ckv; cp.V = ckv + (size_t)d * es; cp.out = att;
+        cp.rows_sB = (long)c->n_sel * Tm * S; cp.rows_sSel = (long)Tm * S;
+        cp.rows = c->rows ? c->rows + (long)b0 * cp.rows_sB : nullptr;
+        cp.row_index = c->st_n_text + b0; cp.active = active;
         for (int h = 0; h < 32; ++h) cp.sel_slot[h] = -1;
         for (int k = 0; k < c->n_sel; ++k)
             if (c->cfg.align_layer[k] == (int)li) cp.sel_slot[c->cfg.align_head[k]] = k;
@@ -499,14 +533,14 @@ int decoder_step(uw_ctx* c, int B, hipStream_t s)
         if (timed) UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used], s));
         RUN(uw_cross_attn_decode(c->dt, cp, s));
         if (timed) { UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used + 1], s)); c->prof_used += 2; }
-        if (c->prof_on) ++c->prof_launches;
-        RUN(gemm(c, c->d_attn, d, l.cross.wo, d, c->d_x, d, true, B, d, d, l.cross.bo, 0, c->d_x, d, s));
-        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.ln2_g, l.ln2_b, B, d, s));
-        RUN(gemm(c, c->d_ln, d, l.w1, d, c->d_mlp, 4 * d, false, B, 4 * d, d, l.b1, 1, nullptr, 0, s));
-        RUN(gemm(c, c->d_mlp, 4 * d, l.w2, 4 * d, c->d_x, d, true, B, d, 4 * d, l.b2, 0, c->d_x, d, s));
+        if (c->prof_on) { ++c->prof_launches; c->prof_windows += B; }
+        RUN(gemm(c, att, d, l.cross.wo, d, x, d, true, B, d, d, l.cross.bo, 0, x, d, s));
+        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.ln2_g, l.ln2_b, B, d, s));
+        RUN(gemm(c, ln, d, l.w1, d, mlp, 4 * d, false, B, 4 * d, d, l.b1, 1, nullptr, 0, s));
+        RUN(gemm(c, mlp, 4 * d, l.w2, 4 * d, x, d, true, B, d, 4 * d, l.b2, 0, x, d, s));
     }
-    RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, c->dec_ln_g, c->dec_ln_b, B, d, s));
-    RUN(gemm(c, c->d_ln, d, c->tok_emb, d, c->logits, c->logits_ld, true, B, c->V, d, nullptr, 0, nullptr, 0, s));
+    RUN(uw_layernorm(c->dt, x, ln, nullptr, c->dec_ln_g, c->dec_ln_b, B, d, s));
+    RUN(gemm(c, ln, d, c->tok_emb, d, logits, c->logits_ld, true, B, c->V, d, nullptr, 0, nullptr, 0, s));
     return UW_OK;
 }
 
@@ -527,7 +561,6 @@ __global__ void greedy_init_kernel(GreedyState st, const int32_t* __restrict__ p
         st.dirty_from[b] = -1;
         st.max_new[b] = budget;
         st.active[b] = budget > 0 ? 1 : 0;
-        if (budget > 0) atomicAdd(st.n_active, 1);
     }
 }
 
@@ -566,6 +599,14 @@ __global__ void copy_tokens_out_kernel(const GreedyState st, const int32_t* __re
         if (n_new) n_new[b] = nn;
         if (n_text) n_text[b] = nt;
     }
+}
+
+__global__ void count_active_kernel(const int32_t* __restrict__ active, int n, int32_t* __restrict__ out)
+{
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += 64) c += active[i] ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (threadIdx.x == 0) *out = c;
 }
 
 __global__ void prompt_rows_kernel(const int32_t* __restrict__ plen, int32_t* __restrict__ q_first, int32_t* __restrict__ q_count, int B)
@@ -636,6 +677,7 @@ int uw_ctx_create(const uw_config* cfg, const void* const* weights, int n_weight
     if (!rc) rc = uw_mel_tables_create(cfg->n_mels, mel_filters, &c->mel_tables);
     if (!rc) rc = load_weights(c, weights, n_weights);
     if (!rc) rc = alloc_workspace(c);
+    if (!rc) rc = create_streams(c);
     if (!rc && hipDeviceSynchronize() != hipSuccess) { uw_set_error("device error during context creation"); rc = UW_ERR_HIP; }
     if (rc) { uw_ctx_destroy(c); return rc; }
     *out = c;
@@ -648,6 +690,11 @@ int uw_ctx_destroy(uw_ctx* c)
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    for (int k = 0; k < 4; ++k) {
+        if (c->sub_stream[k]) (void)hipStreamDestroy(c->sub_stream[k]);
+        if (c->sub_event[k]) (void)hipEventDestroy(c->sub_event[k]);
+    }
+    if (c->fork_event) (void)hipEventDestroy(c->fork_event);
     if (c->host_pin) (void)hipHostFree(c->host_pin);
     uw_mel_tables_destroy(c->mel_tables);
     delete c;
@@ -666,11 +713,12 @@ int uw_profile_begin(uw_ctx* c, int max_launches)
     }
     c->prof_used = 0;
     c->prof_launches = 0;
+    c->prof_windows = 0;
     c->prof_on = true;
     return UW_OK;
 }
 
-int uw_profile_end(uw_ctx* c, int64_t* launches_total, int64_t* launches_timed, double* timed_ms)
+int uw_profile_end(uw_ctx* c, int64_t* launches_total, int64_t* launches_timed, int64_t* windows_total, double* timed_ms)
 {
     UW_REQUIRE(c && c->prof_on, "uw_profile_end: profiling was not started");
     c->prof_on = false;
@@ -682,6 +730,7 @@ int uw_profile_end(uw_ctx* c, int64_t* launches_total, int64_t* launches_timed, 
         ms += t;
     }
     if (launches_total) *launches_total = c->prof_launches;
+    if (windows_total) *windows_total = c->prof_windows;
     if (launches_timed) *launches_timed = (int64_t)(c->prof_used / 2);
     if (timed_ms) *timed_ms = ms;
     return UW_OK;
@@ -743,25 +792,59 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
     int32_t* plen_dev = c->st_zero;   // per-window prompt lengths
     memcpy(c->host_pin, prompt_len_host, (size_t)B * 4);
     UW_HIP_CHECK(hipMemcpyAsync(plen_dev, c->host_pin, (size_t)B * 4, hipMemcpyHostToDevice, s));
-    UW_HIP_CHECK(hipMemsetAsync(c->st_n_active, 0, 4, s));
     GreedyState st = state_of(c);
     hipLaunchKernelGGL(greedy_init_kernel, dim3(B), dim3(256), 0, s, st, prompt_ids, ld_prompt, plen_dev, B, max_tokens, c->Tm);
     UW_LAUNCH_CHECK();
     const int max_steps = std::max(0, std::min(max_tokens, c->Tm) - Pmin);
-    int32_t* h_active = c->host_pin + 4 * c->Bm;
     if (max_steps > 0) {
         // prompt pass: fills the self K/V cache, captures attention row 0, gives the logits of the last prompt position
         hipLaunchKernelGGL(prompt_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, s, plen_dev, c->st_qfirst, c->st_qcount, B);
         UW_LAUNCH_CHECK();
         RUN(decoder_forward(c, c->st_tokens, c->Tm, B, Pmax, c->st_qfirst, c->st_qcount, nullptr, nullptr, true, c->st_pos, 0, s));
+        // split the windows into up to four ranges, one stream each
+        const int n_sub = c->n_streams <= 1 ? 1 : (B >= 64 ? std::min(4, c->n_streams) : (B >= 32 ? 2 : 1));
+        int sub_b0[5];
+        for (int k = 0; k <= n_sub; ++k) sub_b0[k] = (int)((long)B * k / n_sub);
+        hipStream_t ss[4];
+        if (n_sub > 1) {
+            UW_HIP_CHECK(hipEventRecord(c->fork_event, s));
+            for (int k = 0; k < n_sub; ++k) { ss[k] = c->sub_stream[k]; UW_HIP_CHECK(hipStreamWaitEvent(ss[k], c->fork_event, 0)); }
+        } else {
+            ss[0] = s;
+        }
+        int32_t* h_active = c->host_pin + 4 * c->Bm;       // [n_sub] read back every 8 steps
+        bool sub_done[4] = {false, false, false, false};
+        for (int k = 0; k < n_sub; ++k) {
+            // per-range live counters: recount from the active flags
+            hipLaunchKernelGGL(count_active_kernel, dim3(1), dim3(64), 0, ss[k], c->st_active + sub_b0[k], sub_b0[k + 1] - sub_b0[k], c->st_n_active + k);
+            UW_LAUNCH_CHECK();
+        }
         for (int step = 0; step < max_steps; ++step) {
-            if (step > 0) RUN(decoder_step(c, B, s));
-            RUN(uw_argmax_rows(c->logits, c->logits_ld, B, c->V, c->st_next, s));
-            RUN(uw_greedy_advance(st, c->st_next, B, eot, sot, ts_begin, ts_end, s));
-            if ((step & 7) == 7 && step + 1 < max_steps) {
-                UW_HIP_CHECK(hipMemcpyAsync(h_active, c->st_n_active, 4, hipMemcpyDeviceToHost, s));
-                UW_HIP_CHECK(hipStreamSynchronize(s));
-                if (*h_active <= 0) break;
+            bool any = false;
+            for (int k = 0; k < n_sub; ++k) {
+                if (sub_done[k]) continue;
+                any = true;
+                const int b0 = sub_b0[k], Bn = sub_b0[k + 1] - sub_b0[k];
+                GreedyState sk = st;
+                sk.tokens += (long)b0 * st.ld_tok; sk.text_ids += (long)b0 * st.ld_tok;
+                sk.pos += b0; sk.n_new += b0; sk.n_text += b0; sk.active += b0; sk.dirty_from += b0; sk.max_new += b0;
+                sk.n_active = c->st_n_active + k;
+                if (step > 0) RUN(decoder_step(c, b0, Bn, ss[k]));
+                RUN(uw_argmax_rows(c->logits + (long)b0 * c->logits_ld, c->logits_ld, Bn, c->V, c->st_next + b0, ss[k]));
+                RUN(uw_greedy_advance(sk, c->st_next + b0, Bn, eot, sot, ts_begin, ts_end, ss[k]));
+                if ((step & 7) == 7 && step + 1 < max_steps) {
+                    // non-blocking look at the counter copied 8 steps ago, then queue the next copy
+                    if (step >= 15 && hipEventQuery(c->sub_event[k]) == hipSuccess && h_active[k] <= 0) sub_done[k] = true;
+                    UW_HIP_CHECK(hipMemcpyAsync(h_active + k, c->st_n_active + k, 4, hipMemcpyDeviceToHost, ss[k]));
+                    UW_HIP_CHECK(hipEventRecord(c->sub_event[k], ss[k]));
+                }
+            }
+            if (!any) break;
+        }
+        if (n_sub > 1) {
+            for (int k = 0; k < n_sub; ++k) {
+                UW_HIP_CHECK(hipEventRecord(c->sub_event[k], ss[k]));
+                UW_HIP_CHECK(hipStreamWaitEvent(s, c->sub_event[k], 0));
             }
         }
     }

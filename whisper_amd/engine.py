@@ -83,9 +83,9 @@ class Engine:
         L.check(self.lib.uw_profile_begin(self.ctx, int(max_launches)))
 
     def profile_end(self) -> Dict[str, float]:
-        total, timed, ms = C.c_int64(), C.c_int64(), C.c_double()
-        L.check(self.lib.uw_profile_end(self.ctx, C.byref(total), C.byref(timed), C.byref(ms)))
-        return {"launches": total.value, "timed": timed.value, "timed_ms": ms.value}
+        total, timed, windows, ms = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
+        L.check(self.lib.uw_profile_end(self.ctx, C.byref(total), C.byref(timed), C.byref(windows), C.byref(ms)))
+        return {"launches": total.value, "timed": timed.value, "windows": windows.value, "timed_ms": ms.value}
 
     # ---- stages ---------------------------------------------------------------------------------
     def mel(self, audio: torch.Tensor, n_samples: torch.Tensor) -> torch.Tensor:

@@ -54,7 +54,7 @@ SIGNATURES = {
     "uw_transcribe_windows": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int, C.POINTER(_i32), C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uw_profile_begin": (C.c_int, [_vp, C.c_int]),
-    "uw_profile_end": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "uw_profile_end": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None
