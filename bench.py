@@ -121,6 +121,7 @@ def main():
 
     from whisper_amd import engine as E
     from whisper_amd.config import alignment_heads, alignment_heads_key, dims_for
+    from whisper_amd.parallel import gather_results
     from whisper_amd.weights import synthetic_state_dict
 
     dims = dims_for(args.model)
@@ -138,9 +139,8 @@ def main():
     def step():
         res = eng.transcribe_windows(audio, n_samples, prompts, max_tokens, EOT, SOT, TS_BEGIN, TS_END)
         if world > 1:   # the path's only exchange: gather tokens and boundary frames on every rank
-            packed = torch.cat([res["new_tokens"], res["boundaries"], res["n_new"][:, None], res["n_text"][:, None]], dim=1)
-            out = [torch.empty_like(packed) for _ in range(world)]
-            dist.all_gather(out, packed)
+            small = {k: res[k] for k in ("new_tokens", "boundaries", "n_new", "n_text")}
+            gather_results(small, B * world, rank, world)
         return res
 
     def fence():
