@@ -319,9 +319,10 @@ int alloc_workspace(uw_ctx* c)
 // ---- launch sequences -------------------------------------------------------------------------------------
 int gemm(uw_ctx* c, const void* A, long lda, const void* Bw, long ldb, void* C, long ldc, bool out_f32, int M, int N,
          int K, const float* bias, int act, const float* residual, long ldr, hipStream_t s, int batch = 1, long sA = 0,
-         long sB = 0, long sC = 0, long sR = 0, int bias_mode = 1)
+         long sB = 0, long sC = 0, long sR = 0, int bias_mode = 1, long c_group = 0)
 {
     GemmParams p;
+    p.c_group = c_group;
     p.A = A; p.B = Bw; p.C = C; p.bias = bias; p.residual = residual;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.sA = sA; p.sB = sB; p.sC = sC; p.sR = sR;
@@ -329,7 +330,7 @@ int gemm(uw_ctx* c, const void* A, long lda, const void* Bw, long ldb, void* C, 
     p.bias_mode = bias ? bias_mode : 0;
     p.act = act;
     // decode-step shapes: few rows, modest N -> stream the weights once over many small workgroups
-    if (batch == 1 && M <= 128 && N <= 8192) return uw_gemm_skinny(c->dt, out_f32 ? 1 : 0, p, s);
+    if (batch == 1 && M <= 128 && N <= 8192 && !c_group) return uw_gemm_skinny(c->dt, out_f32 ? 1 : 0, p, s);
     return uw_gemm(c->dt, out_f32 ? 1 : 0, p, s);
 }
 
@@ -376,7 +377,9 @@ int cross_kv_project(uw_ctx* c, int B, hipStream_t s)
         auto& a = c->dec[li].cross;
         void* kv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c);
         void* vt = (char*)c->cross_vt + li * cross_vt_layer_bytes(c);
-        RUN(gemm(c, c->enc_T, d, a.wkv, d, kv, 2 * d, false, B * S, 2 * d, d, a.bkv, 0, nullptr, 0, s));
+        // K|V head-contiguous: window b, group g (K heads, then V heads), frame t at ((b*2H + g)*S + t)*64
+        RUN(gemm(c, c->enc_T, d, a.wkv, d, kv, 64, false, S, 2 * d, d, a.bkv, 0, nullptr, 0, s, B, (long)S * d, 0, (long)S * 2 * d, 0, 1,
+                 (long)S * 64));
         RUN(gemm(c, a.wv, d, c->enc_T, d, vt, c->Spad, false, d, S, d, a.bv, 0, nullptr, 0, s, B, 0, (long)S * d, (long)d * c->Spad, 0, 2));
     }
     c->cross_batch = B;
@@ -416,13 +419,13 @@ int decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, con
         // --- causal self-attention ---
         RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.self.ln_g, l.self.ln_b, M, d, s));
         RUN(gemm(c, c->d_ln, d, l.self.wq, d, c->d_qkv, d, false, (int)M, d, d, l.self.bq, 0, nullptr, 0, s));
-        RUN(gemm(c, c->d_ln, d, l.self.wkv, d, skv, 2 * d, false, T, 2 * d, d, l.self.bkv, 0, nullptr, 0, s, B, (long)T * d, 0,
-                 (long)Tm * 2 * d, 0));
+        RUN(gemm(c, c->d_ln, d, l.self.wkv, d, skv, 64, false, T, 2 * d, d, l.self.bkv, 0, nullptr, 0, s, B, (long)T * d, 0,
+                 (long)Tm * 2 * d, 0, 1, (long)Tm * 64));
         RUN(gemm(c, l.self.wv, d, c->d_ln, d, c->d_vt, Tpad, false, d, T, d, l.self.bv, 0, nullptr, 0, s, B, 0, (long)T * d,
                  (long)d * Tpad, 0, 2));
         AttnParams a;
         a.Q = c->d_qkv; a.K = skv; a.VT = c->d_vt; a.O = c->d_attn;
-        a.ldq = d; a.ldk = 2 * d; a.ldvt = Tpad; a.ldo = d;
+        a.ldq = d; a.ldk = 64; a.sKh = (long)Tm * 64; a.ldvt = Tpad; a.ldo = d;
         a.sQ = (long)T * d; a.sK = (long)Tm * 2 * d; a.sVT = (long)d * Tpad; a.sO = (long)T * d;
         a.B = B; a.H = H; a.Sq = T; a.Sk = T; a.causal = 1;
         RUN(uw_flash_attention(c->dt, a, s));
@@ -431,7 +434,7 @@ int decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, con
         RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.cross.ln_g, l.cross.ln_b, M, d, s));
         RUN(gemm(c, c->d_ln, d, l.cross.wq, d, c->d_qkv, d, false, (int)M, d, d, l.cross.bq, 0, nullptr, 0, s));
         ProbParams pp;
-        pp.Q = c->d_qkv; pp.K = ckv; pp.ldq = d; pp.ldk = 2 * d; pp.sQ = (long)T * d; pp.sK = (long)S * 2 * d;
+        pp.Q = c->d_qkv; pp.K = ckv; pp.ldq = d; pp.ldk = 64; pp.sKh = (long)S * 64; pp.sQ = (long)T * d; pp.sK = (long)S * 2 * d;
         pp.B = B; pp.Sq = T; pp.Sk = S;
         if (rows_count && c->n_sel > 0) {
             pp.n_heads_sel = 0;
@@ -455,7 +458,7 @@ int decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, con
             }
         }
         a.Q = c->d_qkv; a.K = ckv; a.VT = cvt; a.O = c->d_attn;
-        a.ldq = d; a.ldk = 2 * d; a.ldvt = c->Spad; a.ldo = d;
+        a.ldq = d; a.ldk = 64; a.sKh = (long)S * 64; a.ldvt = c->Spad; a.ldo = d;
         a.sQ = (long)T * d; a.sK = (long)S * 2 * d; a.sVT = (long)d * c->Spad; a.sO = (long)T * d;
         a.Sq = T; a.Sk = S; a.causal = 0;
         RUN(uw_flash_attention(c->dt, a, s));
@@ -514,21 +517,22 @@ int decoder_step(uw_ctx* c, int b0, int B, hipStream_t s)
         RUN(uw_layernorm(c->dt, x, ln, nullptr, l.self.ln_g, l.self.ln_b, B, d, s));
         RUN(gemm(c, ln, d, l.self.wqkv, d, qkv, 3 * d, false, B, 3 * d, d, l.self.bqkv, 0, nullptr, 0, s));
         SelfDecodeParams sp;
-        sp.qkv = qkv; sp.kcache = skv; sp.vcache = skv + (size_t)d * es; sp.out = att;
-        sp.pos = pos; sp.active = active; sp.ld_cache = 2 * d; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
+        sp.qkv = qkv; sp.kcache = skv; sp.vcache = skv + (size_t)Tm * d * es; sp.out = att;
+        sp.pos = pos; sp.active = active; sp.ld_cache = 64; sp.cache_sB = (long)Tm * 2 * d; sp.cache_sH = (long)Tm * 64; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
         RUN(uw_self_attn_decode(c->dt, sp, s));
         RUN(gemm(c, att, d, l.self.wo, d, x, d, true, B, d, d, l.self.bo, 0, x, d, s));
         RUN(uw_layernorm(c->dt, x, ln, nullptr, l.cross.ln_g, l.cross.ln_b, B, d, s));
         RUN(gemm(c, ln, d, l.cross.wq, d, qkv, d, false, B, d, d, l.cross.bq, 0, nullptr, 0, s));
         CrossDecodeParams cp;
-        cp.q = qkv; cp.K = ckv; cp.V = ckv + (size_t)d * es; cp.out = att;
+        cp.q = qkv; cp.K = ckv; cp.V = ckv + (size_t)S * d * es; cp.out = att;
         cp.rows_sB = (long)c->n_sel * Tm * S; cp.rows_sSel = (long)Tm * S;
         cp.rows = c->rows ? c->rows + (long)b0 * cp.rows_sB : nullptr;
         cp.row_index = c->st_n_text + b0; cp.active = active;
         for (int h = 0; h < 32; ++h) cp.sel_slot[h] = -1;
         for (int k = 0; k < c->n_sel; ++k)
             if (c->cfg.align_layer[k] == (int)li) cp.sel_slot[c->cfg.align_head[k]] = k;
-        cp.B = B; cp.H = H; cp.d = d; cp.S = S; cp.n_rows_max = Tm; cp.ld_kv = 2 * d;
+        cp.B = B; cp.H = H; cp.d = d; cp.S = S; cp.n_rows_max = Tm; cp.ld_kv = 64;
+        cp.kv_sB = (long)S * 2 * d; cp.kv_sH = (long)S * 64;
         const bool timed = c->prof_on && c->prof_used + 2 <= c->prof_ev.size();
         if (timed) UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used], s));
         RUN(uw_cross_attn_decode(c->dt, cp, s));

@@ -56,20 +56,20 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p, ProbParams
     const int b = blockIdx.z;
     int head, Sq, Sk, q_base = 0, q_count;
     const T *Qb, *Kb;
-    long ldq, ldk;
+    long ldq, ldk, sKh;
     if constexpr (PROBS) {
         head = pp.heads[blockIdx.y];
         Sq = pp.Sq; Sk = pp.Sk;
         q_base = pp.q_first ? pp.q_first[b] : 0;
         q_count = pp.q_count ? pp.q_count[b] : Sq;
         Qb = (const T*)pp.Q + b * pp.sQ; Kb = (const T*)pp.K + b * pp.sK;
-        ldq = pp.ldq; ldk = pp.ldk;
+        ldq = pp.ldq; ldk = pp.ldk; sKh = pp.sKh;
     } else {
         head = blockIdx.y;
         Sq = p.Sq; Sk = p.Sk;
         q_count = p.sq_len ? p.sq_len[b] : Sq;
         Qb = (const T*)p.Q + b * p.sQ; Kb = (const T*)p.K + b * p.sK;
-        ldq = p.ldq; ldk = p.ldk;
+        ldq = p.ldq; ldk = p.ldk; sKh = p.sKh;
     }
     const int q0 = blockIdx.x * 128;          // first query of the workgroup, relative to q_base
     if (q0 >= q_count) return;
@@ -85,18 +85,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p, ProbParams
     for (int i = 0; i < L::CH; ++i) {
         const int Lc = i * 256 + tid, row = Lc / L::CPR, c = (Lc % L::CPR) ^ L::swz(row);
         krow[i] = row;
-        srcK[i] = Kb + head * 64 + c * L::E;
+        srcK[i] = Kb + head * sKh + c * L::E;
         if constexpr (!PROBS) srcV[i] = VTb + (long)row * p.ldvt + c * L::E;
     }
+    const unsigned lds_base = lds_addr_of(smem) + __builtin_amdgcn_readfirstlane(wave) * 1024;
     auto stage = [&](int key0, int buf) {
-        char* kd = smem + buf * 2 * L::TILE + wave * 1024;
-        char* vd = kd + L::TILE;
+        const unsigned kd = lds_base + buf * 2 * L::TILE, vd = kd + L::TILE;
 #pragma unroll
         for (int i = 0; i < L::CH; ++i) {
             const int kr = min(key0 + krow[i], Sk - 1);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(srcK[i] + (long)kr * ldk), LDS_PTR(kd + i * 4096), 16, 0, 0);
-            if constexpr (!PROBS)
-                __builtin_amdgcn_global_load_lds(GLB_PTR(srcV[i] + key0), LDS_PTR(vd + i * 4096), 16, 0, 0);
+            glds16(srcK[i] + (long)kr * ldk, kd + i * 4096);
+            if constexpr (!PROBS) glds16(srcV[i] + key0, vd + i * 4096);
         }
     };
 
@@ -155,7 +154,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p, ProbParams
         stage(0, 0);
         for (int j = 0; j < n_tiles; ++j) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             if (j + 1 < n_tiles) stage((j + 1) * 64, (j + 1) & 1);
             const char* Ks = smem + (j & 1) * 2 * L::TILE;
             const char* Vs = Ks + L::TILE;

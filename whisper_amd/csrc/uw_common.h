@@ -40,6 +40,32 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// LDS byte address of a __shared__ pointer, as a provably wave-uniform scalar
+__device__ __forceinline__ unsigned lds_addr_of(const void* p)
+{
+    return __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)LDS_PTR(p));
+}
+// 16-byte-per-lane global -> LDS DMA (lane l lands at lds_addr + 16 * l).  Issued from inline asm so that the
+// compiler does not track it: with the builtin form hipcc drains every outstanding DMA (vmcnt(0)) before the
+// next ds_read, which serialises a multi-stage ring.  The caller orders it: counted s_waitcnt vmcnt(N), then a
+// barrier, then the reads.  M0 is saved and restored inside the statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_addr)
+                 : "memory");
+}
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  This bijection hands each
+// XCD a CONTIGUOUS run of tile indices, so tiles that share an operand panel hit the same L2 (speed only).
+__device__ __forceinline__ int xcd_contiguous_tile(int b, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }

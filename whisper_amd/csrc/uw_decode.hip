@@ -40,6 +40,15 @@ template <typename T> __device__ __forceinline__ float dot_chunk(const uint4& u,
     return s;
 }
 
+// 16-byte load of data that is read once per launch and is far larger than the caches: non-temporal, so it
+// does not evict what the other kernels of the step keep in L2 / Infinity Cache
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ uint4 ld_stream(const void* p)
+{
+    const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // sum over the LPR lanes that share a row
 template <typename T> __device__ __forceinline__ float row_sum(float v)
 {
@@ -64,8 +73,8 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int sub = lane % R::LPR, rin = lane / R::LPR;
     const long ld = p.ld_kv;
-    const T* Kh = (const T*)p.K + (long)b * S * ld + h * 64 + sub * R::E;
-    const T* Vh = (const T*)p.V + (long)b * S * ld + h * 64 + sub * R::E;
+    const T* Kh = (const T*)p.K + (long)b * p.kv_sB + (long)h * p.kv_sH + sub * R::E;
+    const T* Vh = (const T*)p.V + (long)b * p.kv_sB + (long)h * p.kv_sH + sub * R::E;
 
     float q[R::E];
     {
@@ -81,7 +90,7 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int r = r0 + (u * 4 + wave) * R::RPI + rin;
-            kv[u] = *(const uint4*)(Kh + (long)min(r, S - 1) * ld);
+            kv[u] = ld_stream(Kh + (long)min(r, S - 1) * ld);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -89,6 +98,13 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
             const float s = row_sum<T>(dot_chunk<T>(kv[u], q));
             if (sub == 0 && r < S) sc[r] = s;
         }
+    }
+    // the first round of V rows is requested now, so HBM stays busy while the workgroup does its softmax
+    uint4 vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int r = (u * 4 + wave) * R::RPI + rin;
+        vv[u] = ld_stream(Vh + (long)min(r, S - 1) * ld);
     }
     __syncthreads();
     // ---- softmax over S ----
@@ -125,11 +141,12 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
 #pragma unroll
     for (int e = 0; e < R::E; ++e) acc[e] = 0.f;
     for (int r0 = 0; r0 < S; r0 += rows_per_round) {
-        uint4 vv[U];
+        if (r0 > 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
-            vv[u] = *(const uint4*)(Vh + (long)min(r, S - 1) * ld);
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+                vv[u] = ld_stream(Vh + (long)min(r, S - 1) * ld);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -175,8 +192,8 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
     const int sub = lane % R::LPR, rin = lane / R::LPR;
     const long ld = p.ld_cache;
     const T* qkv = (const T*)p.qkv + (long)b * 3 * p.d + h * 64 + sub * R::E;
-    T* Kc = (T*)p.kcache + (long)b * p.n_ctx * ld + h * 64 + sub * R::E;
-    T* Vc = (T*)p.vcache + (long)b * p.n_ctx * ld + h * 64 + sub * R::E;
+    T* Kc = (T*)p.kcache + (long)b * p.cache_sB + (long)h * p.cache_sH + sub * R::E;
+    T* Vc = (T*)p.vcache + (long)b * p.cache_sB + (long)h * p.cache_sH + sub * R::E;
     const uint4 knew = *(const uint4*)(qkv + p.d), vnew = *(const uint4*)(qkv + 2 * p.d);
     if (wave == 0 && rin == 0) {
         *(uint4*)(Kc + (long)pos * ld) = knew;
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
         for (int u = 0; u < U; ++u) {
             const int r = r0 + (u * 4 + wave) * R::RPI + rin;
             kv[u] = knew;
-            if (r < pos) kv[u] = *(const uint4*)(Kc + (long)r * ld);
+            if (r < pos) kv[u] = ld_stream(Kc + (long)r * ld);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -229,7 +246,7 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
         for (int u = 0; u < U; ++u) {
             const int r = r0 + (u * 4 + wave) * R::RPI + rin;
             vv[u] = vnew;
-            if (r < pos) vv[u] = *(const uint4*)(Vc + (long)r * ld);
+            if (r < pos) vv[u] = ld_stream(Vc + (long)r * ld);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -294,7 +311,7 @@ __global__ void greedy_advance_kernel(GreedyState st, const int32_t* __restrict_
 
 int uw_cross_attn_decode(int dtype, const CrossDecodeParams& p, hipStream_t s)
 {
-    UW_REQUIRE(p.q && p.K && p.V && p.out && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.S > 0 && p.S <= 4096 && p.ld_kv >= p.d,
+    UW_REQUIRE(p.q && p.K && p.V && p.out && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.S > 0 && p.S <= 4096 && p.ld_kv >= 64,
                "cross_attn_decode: bad arguments");
     UW_REQUIRE(!p.rows || p.row_index, "cross_attn_decode: rows without row_index");
     const size_t lds = (size_t)(((p.S + 63) & ~63) + 8 + 256) * 4;
@@ -307,7 +324,7 @@ int uw_cross_attn_decode(int dtype, const CrossDecodeParams& p, hipStream_t s)
 
 int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s)
 {
-    UW_REQUIRE(p.qkv && p.kcache && p.vcache && p.out && p.pos && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.n_ctx <= 512 && p.ld_cache >= p.d,
+    UW_REQUIRE(p.qkv && p.kcache && p.vcache && p.out && p.pos && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.n_ctx <= 512 && p.ld_cache >= 64,
                "self_attn_decode: bad arguments");
     const dim3 grid(p.H, p.B);
     if (dtype == UW_F32) hipLaunchKernelGGL(self_decode_kernel<float>, grid, dim3(256), 0, s, p);

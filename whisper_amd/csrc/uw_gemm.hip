@@ -13,8 +13,15 @@
 // row m and the epilogue stores 8/16 contiguous bytes per lane.
 #include "uw_common.h"
 #include "uw_kernels.h"
+#include <stdlib.h>
 
 namespace {
+
+// element offset of C[m][n] inside one batch item (see GemmParams::c_group)
+__device__ __forceinline__ long c_off(const GemmParams& p, long m, int n)
+{
+    return p.c_group ? (long)(n >> 6) * p.c_group + m * p.ldc + (n & 63) : m * p.ldc + n;
+}
 
 constexpr int BM = 128, BN = 128, KB = 128;  // KB: bytes of K per tile row
 constexpr int TILE_BYTES = BM * KB;          // 16 KiB per operand per buffer
@@ -28,7 +35,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const long bz = blockIdx.y;
     const T* __restrict__ A = (const T*)p.A + bz * p.sA;
@@ -44,13 +51,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p)
         srcA[i] = A + (long)gm * p.lda + c * E;
         srcB[i] = B + (long)gn * p.ldb + c * E;
     }
+    const unsigned lds_base = lds_addr_of(smem) + __builtin_amdgcn_readfirstlane(wave) * 1024;
     auto stage = [&](int kt, int buf) {
-        char* a_dst = smem + buf * 2 * TILE_BYTES + wave * 1024;
-        char* b_dst = a_dst + TILE_BYTES;
+        const unsigned a_dst = lds_base + buf * 2 * TILE_BYTES, b_dst = a_dst + TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(srcA[i] + (long)kt * KT), LDS_PTR(a_dst + i * 4096), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(srcB[i] + (long)kt * KT), LDS_PTR(b_dst + i * 4096), 16, 0, 0);
+            glds16(srcA[i] + (long)kt * KT, a_dst + i * 4096);
+            glds16(srcB[i] + (long)kt * KT, b_dst + i * 4096);
         }
     };
 
@@ -64,9 +71,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p)
     const int frow = lane & 15, fg = lane >> 4;
     stage(0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile kt landed (this wave's pieces)
+        __builtin_amdgcn_s_barrier();                       // ... everyone's; and tile kt-1 is no longer being read
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);       // overlaps the MFMAs below
         const char* As = smem + (kt & 1) * 2 * TILE_BYTES;
         const char* Bs = As + TILE_BYTES;
 #pragma unroll
@@ -112,11 +120,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p)
                     v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
                 }
                 if constexpr (sizeof(TC) == 4) {
-                    *(f32x4*)((float*)C + (long)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+                    *(f32x4*)((float*)C + c_off(p, m, n)) = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
                     union { bf16_t h[4]; uint2 u; } pk;
                     pk.h[0] = (bf16_t)v[0]; pk.h[1] = (bf16_t)v[1]; pk.h[2] = (bf16_t)v[2]; pk.h[3] = (bf16_t)v[3];
-                    *(uint2*)((bf16_t*)C + (long)m * p.ldc + n) = pk.u;
+                    *(uint2*)((bf16_t*)C + c_off(p, m, n)) = pk.u;
                 }
             } else {
 #pragma unroll
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p)
                     if (n + r >= p.N) break;
                     float x = v[r];
                     if (R) x += R[(long)m * p.ldr + n + r];
-                    C[(long)m * p.ldc + n + r] = from_f32<TC>(x);
+                    C[c_off(p, m, n) + r] = from_f32<TC>(x);
                 }
             }
         }
@@ -148,6 +156,171 @@ template <typename T, typename TC> int launch(const GemmParams& p, hipStream_t s
 }
 
 // ------------------------------------------------------------------------------------------------
+// Large-M form: 256 x 128 tile, 8 waves (4 x 2, 64 x 64 each), three-stage LDS ring filled by global_load_lds.
+// Two K-tiles stay in flight while one is consumed: the wait before each barrier is a COUNTED vmcnt that
+// retires only the oldest stage, and the barrier is the raw s_barrier (a __syncthreads() would drain the DMA).
+// The epilogue parks the f32 tile in the (now idle) ring and leaves as whole 128/256-byte row segments.
+constexpr int B2M = 256, B2N = 128;
+constexpr int A2_BYTES = B2M * KB, B2_BYTES = B2N * KB, STAGE2 = A2_BYTES + B2_BYTES;   // 48 KiB
+constexpr int NSTAGE2 = 3;
+constexpr int EP_PITCH = 68;   // floats per staged row (64 + 4: conflict-free 16-byte LDS writes)
+
+template <typename T, typename TC>
+__global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = 16 / (int)sizeof(T);
+    constexpr int KT = KB / (int)sizeof(T);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (p.N + B2N - 1) / B2N;
+    const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * B2M, n0 = (tile % tiles_n) * B2N;
+    const long bz = blockIdx.y;
+    const T* __restrict__ A = (const T*)p.A + bz * p.sA;
+    const T* __restrict__ B = (const T*)p.B + bz * p.sB;
+
+    const T* srcA[4];
+    const T* srcB[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int L = i * 512 + tid, row = L >> 3, c = (L & 7) ^ (row & 7);
+        srcA[i] = A + (long)min(m0 + row, p.M - 1) * p.lda + c * E;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = i * 512 + tid, row = L >> 3, c = (L & 7) ^ (row & 7);
+        srcB[i] = B + (long)min(n0 + row, p.N - 1) * p.ldb + c * E;
+    }
+    const unsigned lds_base = lds_addr_of(smem) + wave * 1024;
+    auto stage = [&](int kt, int st) {
+        const unsigned a_dst = lds_base + st * STAGE2, b_dst = a_dst + A2_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(srcA[i] + (long)kt * KT, a_dst + i * 8192);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(srcB[i] + (long)kt * KT, b_dst + i * 8192);
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / KT;
+    const int frow = lane & 15, fg = lane >> 4;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's six DMA pieces of tile kt are older than the six of tile kt+1
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) stage(kt + 2, (kt + 2) % NSTAGE2);
+        const char* As = smem + (kt % NSTAGE2) * STAGE2;
+        const char* Bs = As + A2_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int pos = ((ks * 4 + fg) ^ (frow & 7)) << 4;
+            uint4 af[4], bf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const uint4*)(As + (wr * 64 + t * 16 + frow) * KB + pos);
+                bf[t] = *(const uint4*)(Bs + (wc * 64 + t * 16 + frow) * KB + pos);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) mma16<T>(bf[tn], af[tm], acc[tm][tn]);
+        }
+    }
+    // ---- epilogue: bias / activation in registers, f32 tile through LDS, coalesced residual add + store ----
+    __syncthreads();
+    float* ep = (float*)smem + wave * (64 * EP_PITCH);
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+        const int ml = tm * 16 + frow;
+        const int m = m0 + wr * 64 + ml;
+        const float bias_m = (p.bias_mode == 2 && m < p.M) ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            const int nl = tn * 16 + fg * 4;
+            const int n = n0 + wc * 64 + nl;
+            f32x4 v = acc[tm][tn];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (p.bias_mode == 1) v[r] += (n + r < p.N) ? p.bias[n + r] : 0.f;
+                else v[r] += bias_m;
+                if (p.act == 1) v[r] = gelu_erf(v[r]);
+            }
+            *(f32x4*)(ep + ml * EP_PITCH + nl) = v;
+        }
+    }
+    // the wave reads back only what it wrote: no workgroup barrier needed, LDS ops of a wave are ordered
+    TC* __restrict__ C = (TC*)p.C + bz * p.sC;
+    const float* __restrict__ R = p.residual ? p.residual + bz * p.sR : nullptr;
+    const int nbase = n0 + wc * 64, mbase = m0 + wr * 64;
+    if constexpr (sizeof(TC) == 4) {
+        const bool vec_ok = ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int ml = it * 4 + (lane >> 4), nl = (lane & 15) * 4;
+            const int m = mbase + ml, n = nbase + nl;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v = *(const f32x4*)(ep + ml * EP_PITCH + nl);
+            if (vec_ok && n + 3 < p.N) {
+                if (R) v += *(const f32x4*)(R + (long)m * p.ldr + n);
+                *(f32x4*)((float*)C + c_off(p, m, n)) = v;
+            } else {
+                for (int r = 0; r < 4 && n + r < p.N; ++r)
+                    ((float*)C)[c_off(p, m, n) + r] = v[r] + (R ? R[(long)m * p.ldr + n + r] : 0.f);
+            }
+        }
+    } else {
+        const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) && !R;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int ml = it * 8 + (lane >> 3), nl = (lane & 7) * 8;
+            const int m = mbase + ml, n = nbase + nl;
+            if (m >= p.M || n >= p.N) continue;
+            const f32x4 v0 = *(const f32x4*)(ep + ml * EP_PITCH + nl), v1 = *(const f32x4*)(ep + ml * EP_PITCH + nl + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (vec_ok && n + 7 < p.N) {
+                union { bf16_t h[8]; uint4 u; } pk;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) pk.h[r] = (bf16_t)v[r];
+                *(uint4*)((bf16_t*)C + c_off(p, m, n)) = pk.u;
+            } else {
+                for (int r = 0; r < 8 && n + r < p.N; ++r)
+                    C[c_off(p, m, n) + r] = from_f32<TC>(v[r] + (R ? R[(long)m * p.ldr + n + r] : 0.f));
+            }
+        }
+    }
+}
+
+template <typename T, typename TC> int launch_big(const GemmParams& p, hipStream_t s)
+{
+    constexpr int KT = KB / (int)sizeof(T);
+    UW_REQUIRE(p.K % KT == 0, "gemm: K=%d must be a multiple of %d", p.K, KT);
+    UW_REQUIRE((p.lda * sizeof(T)) % 16 == 0 && (p.ldb * sizeof(T)) % 16 == 0 && (p.sA * sizeof(T)) % 16 == 0 &&
+                   (p.sB * sizeof(T)) % 16 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0,
+               "gemm: operand rows must be 16-byte aligned");
+    const long tiles = (long)ceil_div(p.M, B2M) * ceil_div(p.N, B2N);
+    UW_REQUIRE(tiles < (1l << 31) && p.batch < 65536, "gemm: grid too large");
+    const size_t lds = (size_t)NSTAGE2 * STAGE2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_big_kernel<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_big_kernel<T, TC>), dim3((unsigned)tiles, (unsigned)p.batch), dim3(512), lds, s, p);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Skinny form for the decode step (M = windows in flight <= 128): the weight matrix is streamed exactly
 // once, 16 output columns per workgroup so that even N = d_model gives dozens of workgroups.  The step is
 // latency-bound, not bandwidth-bound, so the 8 waves of a workgroup split K and every wave issues the
@@ -155,7 +328,7 @@ template <typename T, typename TC> int launch(const GemmParams& p, hipStream_t s
 // are combined through LDS in a fixed order (results are run-to-run identical).  Activations (<= 128 rows)
 // stay L2-resident and are read as MFMA fragments straight from global memory.
 constexpr int SK_WAVES = 8;
-constexpr int SK_ROUND = 3;   // K-steps whose loads are in flight together
+constexpr int SK_ROUND = 2;   // K-steps per register buffer; two buffers are in flight
 
 template <typename T, typename TC, int MT>
 __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p)
@@ -187,33 +360,41 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
     auto ld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) -> uint4 {
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     };
-    int s = s_begin;
-    for (; s + SK_ROUND <= s_end; s += SK_ROUND) {      // full rounds: every load issued before the first MFMA
-        const int koff = s * KS * ES;
-        uint4 wv[SK_ROUND], av[SK_ROUND][MT];
+    // Rounds of SK_ROUND K-steps, double-buffered in registers: the loads of round r+1 are issued before the
+    // MFMAs of round r, so a wave pays the memory latency once, not once per round.
+    uint4 wv[2][SK_ROUND], av[2][SK_ROUND][MT];
+    auto load_round = [&](int buf, int s) {
 #pragma unroll
         for (int r = 0; r < SK_ROUND; ++r) {
-            wv[r] = ld(rsW, woff + r * KS * ES, koff);
+            const int koff = min(s + r, s_end - 1) * KS * ES;   // steps past the end re-read the last one (unused)
+            wv[buf][r] = ld(rsW, woff, koff);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[r][mt] = ld(rsA, aoff[mt] + r * KS * ES, koff);
+            for (int mt = 0; mt < MT; ++mt) av[buf][r][mt] = ld(rsA, aoff[mt], koff);
         }
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mma_round = [&](int buf, int s) {
 #pragma unroll
-        for (int r = 0; r < SK_ROUND; ++r)
+        for (int r = 0; r < SK_ROUND; ++r) {
+            if (s + r < s_end) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) mma16<T>(wv[r], av[r][mt], acc[mt]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    for (; s < s_end; ++s) {                            // leftover steps
-        const int koff = s * KS * ES;
-        const uint4 wv = ld(rsW, woff, koff);
-        uint4 av[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) av[mt] = ld(rsA, aoff[mt], koff);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) mma16<T>(wv, av[mt], acc[mt]);
-        __builtin_amdgcn_sched_barrier(0);
+                for (int mt = 0; mt < MT; ++mt) mma16<T>(wv[buf][r], av[buf][r][mt], acc[mt]);
+            }
+        }
+    };
+    if (s_begin < s_end) {
+        load_round(0, s_begin);
+        for (int s = s_begin; s < s_end; s += 2 * SK_ROUND) {
+            if (s + SK_ROUND < s_end) load_round(1, s + SK_ROUND);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_round(0, s);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + SK_ROUND < s_end) {
+                if (s + 2 * SK_ROUND < s_end) load_round(0, s + 2 * SK_ROUND);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_round(1, s + SK_ROUND);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) part[(wave * MT + mt) * 64 + lane] = acc[mt];
@@ -241,11 +422,11 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
             v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
         }
         if constexpr (sizeof(TC) == 4) {
-            *(f32x4*)((float*)C + (long)m * p.ldc + n) = f32x4{v[0], v[1], v[2], v[3]};
+            *(f32x4*)((float*)C + c_off(p, m, n)) = f32x4{v[0], v[1], v[2], v[3]};
         } else {
             union { bf16_t h[4]; uint2 u; } pk;
             pk.h[0] = (bf16_t)v[0]; pk.h[1] = (bf16_t)v[1]; pk.h[2] = (bf16_t)v[2]; pk.h[3] = (bf16_t)v[3];
-            *(uint2*)((bf16_t*)C + (long)m * p.ldc + n) = pk.u;
+            *(uint2*)((bf16_t*)C + c_off(p, m, n)) = pk.u;
         }
     } else {
 #pragma unroll
@@ -253,7 +434,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
             if (n + r >= p.N) break;
             float x = v[r];
             if (R) x += R[(long)m * p.ldr + n + r];
-            C[(long)m * p.ldc + n + r] = from_f32<TC>(x);
+            C[c_off(p, m, n) + r] = from_f32<TC>(x);
         }
     }
 }
@@ -293,6 +474,12 @@ int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
 
 int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
 {
+    static const bool use_big = !(getenv("UW_GEMM_BIG") && atoi(getenv("UW_GEMM_BIG")) == 0);
+    if (use_big && p.M >= 512) {   // enough rows to fill 256-row tiles
+        if (dtype == UW_F32) return launch_big<float, float>(p, s);
+        if (out_f32) return launch_big<bf16_t, float>(p, s);
+        return launch_big<bf16_t, bf16_t>(p, s);
+    }
     if (dtype == UW_F32) return launch<float, float>(p, s);
     if (out_f32) return launch<bf16_t, float>(p, s);
     return launch<bf16_t, bf16_t>(p, s);

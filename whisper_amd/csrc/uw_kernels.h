@@ -20,6 +20,8 @@ struct GemmParams {
     int M = 0, N = 0, K = 0, batch = 1;
     int bias_mode = 0;  // 0 none, 1 bias[n], 2 bias[m]
     int act = 0;        // 0 none, 1 GELU(erf)
+    long c_group = 0;   // 0: C[m][n] at m*ldc + n.  Else columns are stored in groups of 64 (one attention head):
+                        // C[m][n] at (n / 64) * c_group + m * ldc + (n % 64), ldc = 64 for a head-contiguous cache
 };
 // dtype: element type of A and B.  out_f32: C is f32 even when dtype is bf16 (always f32 for UW_F32).
 int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
@@ -52,6 +54,7 @@ struct AttnParams {
     const void* VT = nullptr;  // [B][H*64][ldvt]  (V transposed: row = h*64 + hd, column = key)
     void* O = nullptr;         // [B][Sq][ldo]
     long ldq = 0, ldk = 0, ldvt = 0, ldo = 0;
+    long sKh = 64;             // head stride of K (elements): 64 when heads are columns of a row, Sk*64 when head-contiguous
     long sQ = 0, sK = 0, sVT = 0, sO = 0;  // per-window strides (elements)
     int B = 0, H = 0, Sq = 0, Sk = 0;
     int causal = 0;            // query i sees keys <= i + (Sk - Sq)
@@ -64,6 +67,7 @@ struct ProbParams {
     const void* K = nullptr;  // [B][Sk][ldk]
     float* P = nullptr;       // rows[b][sel][n][Sk]  (n = query index - q_first[b])
     long ldq = 0, ldk = 0, sQ = 0, sK = 0;
+    long sKh = 64;              // head stride of K (elements)
     long sP_b = 0, sP_sel = 0;  // strides of P in floats; row stride is Sk
     int B = 0, Sq = 0, Sk = 0;
     int n_heads_sel = 0;
@@ -77,20 +81,21 @@ int uw_attention_probs(int dtype, const ProbParams& p, hipStream_t s);
 // ---- uw_decode.hip ----------------------------------------------------------------------------
 struct SelfDecodeParams {
     const void* qkv = nullptr;  // [B][3d] (q scaled | k | v) of the current token
-    void* kcache = nullptr;     // [B][n_ctx][d] for this layer
+    void* kcache = nullptr;     // this layer's cache: element (b, h, r, e) at b*cache_sB + h*cache_sH + r*ld_cache + e
     void* vcache = nullptr;
     void* out = nullptr;        // [B][d]
     const int32_t* pos = nullptr;     // per window position of the current token
     const int32_t* active = nullptr;  // per window: 0 = finished (skip)
-    long ld_cache = 0;          // row stride of the caches (elements); 2*d when K and V rows are interleaved
+    long ld_cache = 0;          // row stride of the caches (elements)
+    long cache_sB = 0, cache_sH = 0;  // window and head strides of the caches (elements)
     int B = 0, H = 0, d = 0, n_ctx = 0;
 };
 int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s);
 
 struct CrossDecodeParams {
     const void* q = nullptr;   // [B][d] scaled
-    const void* K = nullptr;   // [B][S][d] for this layer
-    const void* V = nullptr;   // [B][S][d]
+    const void* K = nullptr;   // this layer: element (b, h, r, e) at b*kv_sB + h*kv_sH + r*ld_kv + e
+    const void* V = nullptr;
     void* out = nullptr;       // [B][d]
     float* rows = nullptr;     // attention rows [B][n_sel][n_rows_max][S] or null
     long rows_sB = 0, rows_sSel = 0;
@@ -98,6 +103,7 @@ struct CrossDecodeParams {
     const int32_t* active = nullptr;
     int sel_slot[32];          // per head: slot in [n_sel] or -1
     long ld_kv = 0;            // row stride of K and V (elements)
+    long kv_sB = 0, kv_sH = 0; // window and head strides of K and V (elements)
     int B = 0, H = 0, d = 0, S = 0, n_rows_max = 0;
 };
 int uw_cross_attn_decode(int dtype, const CrossDecodeParams& p, hipStream_t s);
