@@ -31,10 +31,12 @@ struct AttnW {            // one attention block
     void* wo = nullptr;
     float* bo = nullptr;
     float *ln_g = nullptr, *ln_b = nullptr;
+    void *wqkv_p = nullptr, *wq_p = nullptr, *wo_p = nullptr;   // fragment-major copies for the decode step
 };
 struct LayerW {
     AttnW self, cross;
     void *w1 = nullptr, *w2 = nullptr;
+    void *w1_p = nullptr, *w2_p = nullptr;
     float *b1 = nullptr, *b2 = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
 };
 
@@ -249,6 +251,22 @@ int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
         RUN(load_attn(c, cur, l.cross, 2));
         RUN(load_mlp(c, cur, l));
     }
+    // the KV-cached step reads its weights as whole MFMA operand blocks: second, fragment-major copy
+    for (auto& l : c->dec) {
+        const long f = 4 * d;
+        ALLOC(l.self.wqkv_p, 3 * d * d * c->es, false);
+        ALLOC(l.self.wo_p, d * d * c->es, false);
+        ALLOC(l.cross.wq_p, d * d * c->es, false);
+        ALLOC(l.cross.wo_p, d * d * c->es, false);
+        ALLOC(l.w1_p, f * d * c->es, false);
+        ALLOC(l.w2_p, d * f * c->es, false);
+        RUN(uw_pack_frag(c->dt, l.self.wqkv, d, l.self.wqkv_p, (int)(3 * d), (int)d, 0));
+        RUN(uw_pack_frag(c->dt, l.self.wo, d, l.self.wo_p, (int)d, (int)d, 0));
+        RUN(uw_pack_frag(c->dt, l.cross.wq, d, l.cross.wq_p, (int)d, (int)d, 0));
+        RUN(uw_pack_frag(c->dt, l.cross.wo, d, l.cross.wo_p, (int)d, (int)d, 0));
+        RUN(uw_pack_frag(c->dt, l.w1, d, l.w1_p, (int)f, (int)d, 0));
+        RUN(uw_pack_frag(c->dt, l.w2, f, l.w2_p, (int)d, (int)f, 0));
+    }
     const float *dlg = cur.next(), *dlb = cur.next();
     ALLOC(c->dec_ln_g, d * 4, false);
     ALLOC(c->dec_ln_b, d * 4, false);
@@ -332,6 +350,19 @@ int gemm(uw_ctx* c, const void* A, long lda, const void* Bw, long ldb, void* C, 
     // decode-step shapes: few rows, modest N -> stream the weights once over many small workgroups
     if (batch == 1 && M <= 128 && N <= 8192 && !c_group) return uw_gemm_skinny(c->dt, out_f32 ? 1 : 0, p, s);
     return uw_gemm(c->dt, out_f32 ? 1 : 0, p, s);
+}
+
+// decode-step product: A [M][K] and W [N][K] fragment-major, C row-major (or fragment-major when c_packed)
+int gemm_step(uw_ctx* c, const void* A, const void* Wp, void* C, long ldc, bool out_f32, int M, int N, int K, const float* bias,
+              int act, const float* residual, long ldr, bool c_packed, hipStream_t s)
+{
+    GemmParams p;
+    p.A = A; p.B = Wp; p.C = C; p.bias = bias; p.residual = residual;
+    p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K;
+    p.bias_mode = bias ? 1 : 0;
+    p.act = act;
+    p.ab_packed = 1; p.c_packed = c_packed ? 1 : 0;
+    return uw_gemm_skinny(c->dt, out_f32 ? 1 : 0, p, s);
 }
 
 int encoder_forward(uw_ctx* c, const float* mel, int B, hipStream_t s)
@@ -514,15 +545,15 @@ int decoder_step(uw_ctx* c, int b0, int B, hipStream_t s)
         auto& l = c->dec[li];
         char* skv = (char*)c->self_kv + li * self_kv_layer_bytes(c) + (size_t)b0 * Tm * 2 * d * es;
         char* ckv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c) + (size_t)b0 * S * 2 * d * es;
-        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.self.ln_g, l.self.ln_b, B, d, s));
-        RUN(gemm(c, ln, d, l.self.wqkv, d, qkv, 3 * d, false, B, 3 * d, d, l.self.bqkv, 0, nullptr, 0, s));
+        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.self.ln_g, l.self.ln_b, B, d, s, 1));
+        RUN(gemm_step(c, ln, l.self.wqkv_p, qkv, 3 * d, false, B, 3 * d, d, l.self.bqkv, 0, nullptr, 0, false, s));
         SelfDecodeParams sp;
         sp.qkv = qkv; sp.kcache = skv; sp.vcache = skv + (size_t)Tm * d * es; sp.out = att;
-        sp.pos = pos; sp.active = active; sp.ld_cache = 64; sp.cache_sB = (long)Tm * 2 * d; sp.cache_sH = (long)Tm * 64; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
+        sp.pos = pos; sp.active = active; sp.ld_cache = 64; sp.cache_sB = (long)Tm * 2 * d; sp.cache_sH = (long)Tm * 64; sp.out_packed = 1; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
         RUN(uw_self_attn_decode(c->dt, sp, s));
-        RUN(gemm(c, att, d, l.self.wo, d, x, d, true, B, d, d, l.self.bo, 0, x, d, s));
-        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.cross.ln_g, l.cross.ln_b, B, d, s));
-        RUN(gemm(c, ln, d, l.cross.wq, d, qkv, d, false, B, d, d, l.cross.bq, 0, nullptr, 0, s));
+        RUN(gemm_step(c, att, l.self.wo_p, x, d, true, B, d, d, l.self.bo, 0, x, d, false, s));
+        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.cross.ln_g, l.cross.ln_b, B, d, s, 1));
+        RUN(gemm_step(c, ln, l.cross.wq_p, qkv, d, false, B, d, d, l.cross.bq, 0, nullptr, 0, false, s));
         CrossDecodeParams cp;
         cp.q = qkv; cp.K = ckv; cp.V = ckv + (size_t)S * d * es; cp.out = att;
         cp.rows_sB = (long)c->n_sel * Tm * S; cp.rows_sSel = (long)Tm * S;
@@ -531,17 +562,17 @@ int decoder_step(uw_ctx* c, int b0, int B, hipStream_t s)
         for (int h = 0; h < 32; ++h) cp.sel_slot[h] = -1;
         for (int k = 0; k < c->n_sel; ++k)
             if (c->cfg.align_layer[k] == (int)li) cp.sel_slot[c->cfg.align_head[k]] = k;
-        cp.B = B; cp.H = H; cp.d = d; cp.S = S; cp.n_rows_max = Tm; cp.ld_kv = 64;
+        cp.out_packed = 1; cp.B = B; cp.H = H; cp.d = d; cp.S = S; cp.n_rows_max = Tm; cp.ld_kv = 64;
         cp.kv_sB = (long)S * 2 * d; cp.kv_sH = (long)S * 64;
         const bool timed = c->prof_on && c->prof_used + 2 <= c->prof_ev.size();
         if (timed) UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used], s));
         RUN(uw_cross_attn_decode(c->dt, cp, s));
         if (timed) { UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used + 1], s)); c->prof_used += 2; }
         if (c->prof_on) { ++c->prof_launches; c->prof_windows += B; }
-        RUN(gemm(c, att, d, l.cross.wo, d, x, d, true, B, d, d, l.cross.bo, 0, x, d, s));
-        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.ln2_g, l.ln2_b, B, d, s));
-        RUN(gemm(c, ln, d, l.w1, d, mlp, 4 * d, false, B, 4 * d, d, l.b1, 1, nullptr, 0, s));
-        RUN(gemm(c, mlp, 4 * d, l.w2, 4 * d, x, d, true, B, d, 4 * d, l.b2, 0, x, d, s));
+        RUN(gemm_step(c, att, l.cross.wo_p, x, d, true, B, d, d, l.cross.bo, 0, x, d, false, s));
+        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.ln2_g, l.ln2_b, B, d, s, 1));
+        RUN(gemm_step(c, ln, l.w1_p, mlp, 4 * d, false, B, 4 * d, d, l.b1, 1, nullptr, 0, true, s));
+        RUN(gemm_step(c, mlp, l.w2_p, x, d, true, B, d, 4 * d, l.b2, 0, x, d, false, s));
     }
     RUN(uw_layernorm(c->dt, x, ln, nullptr, c->dec_ln_g, c->dec_ln_b, B, d, s));
     RUN(gemm(c, ln, d, c->tok_emb, d, logits, c->logits_ld, true, B, c->V, d, nullptr, 0, nullptr, 0, s));
@@ -808,7 +839,8 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
         // split the windows into up to four ranges, one stream each
         const int n_sub = c->n_streams <= 1 ? 1 : (B >= 64 ? std::min(4, c->n_streams) : (B >= 32 ? 2 : 1));
         int sub_b0[5];
-        for (int k = 0; k <= n_sub; ++k) sub_b0[k] = (int)((long)B * k / n_sub);
+        // ranges start on multiples of 16 windows: the step's fragment-major activations are laid out in 16-row bands
+        for (int k = 0; k <= n_sub; ++k) sub_b0[k] = k == n_sub ? B : std::min(B, (int)(((long)B * k / n_sub + 15) & ~15l));
         hipStream_t ss[4];
         if (n_sub > 1) {
             UW_HIP_CHECK(hipEventRecord(c->fork_event, s));

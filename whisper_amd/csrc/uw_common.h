@@ -106,6 +106,18 @@ template <> __device__ __forceinline__ void mma32<float>(const uint4& a, const u
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
+// "Fragment-major" operand layout of the decode-step GEMMs.  A [R][K] matrix is cut into blocks of 16 rows x
+// 64 bytes of K; inside a block the 16-byte chunk c (0..3) of row r sits at lane position c * 16 + (r & 15), i.e.
+// exactly where the MFMA 16x16 operand wants it, so a wave fetches one operand block as 1 KiB of consecutive
+// bytes instead of sixteen 64-byte pieces of sixteen rows.  Blocks are ordered [row block][K block]; a band of
+// 16 rows occupies the same bytes as in the row-major layout.  Returns the element offset of X[r][k].
+template <typename T> __host__ __device__ __forceinline__ long frag_elem_offset(long r, int k, int K)
+{
+    constexpr int E = 16 / (int)sizeof(T);
+    const int chunk = k / E, steps = K / (4 * E);
+    return (((((r >> 4) * steps + (chunk >> 2)) << 6) + ((chunk & 3) << 4) + (r & 15)) * E) + (k % E);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float wave_sum(float v)

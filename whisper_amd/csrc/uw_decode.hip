@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
     __syncthreads();
     if (tid < 64) {
         const float o = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
-        ((T*)p.out)[(long)b * p.d + h * 64 + tid] = from_f32<T>(o);
+        const long at = p.out_packed ? frag_elem_offset<T>(b, h * 64 + tid, p.d) : (long)b * p.d + h * 64 + tid;
+        ((T*)p.out)[at] = from_f32<T>(o);
     }
 }
 
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
     __syncthreads();
     if (tid < 64) {
         const float o = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
-        ((T*)p.out)[(long)b * p.d + h * 64 + tid] = from_f32<T>(o);
+        const long at = p.out_packed ? frag_elem_offset<T>(b, h * 64 + tid, p.d) : (long)b * p.d + h * 64 + tid;
+        ((T*)p.out)[at] = from_f32<T>(o);
     }
 }
 

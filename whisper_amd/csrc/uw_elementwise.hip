@@ -10,7 +10,7 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, T* __restrict__ y,
                                                         float* __restrict__ y32, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, long rows, int d)
+                                                        const float* __restrict__ beta, long rows, int d, int packed)
 {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -51,13 +51,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mean) * rstd * g[k] + bb[k];
             if (y32) ((f32x4*)(y32 + row * d))[c] = o;
             if (y) {
+                // four consecutive columns never straddle a 16-byte chunk, so they stay contiguous when packed
+                T* dst = packed ? y + frag_elem_offset<T>(row, c * 4, d) : y + row * d + c * 4;
                 if constexpr (sizeof(T) == 4) {
-                    ((f32x4*)(y + row * d))[c] = o;
+                    *(f32x4*)dst = o;
                 } else {
                     union { bf16_t h[4]; uint2 u; } pk;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) pk.h[k] = (bf16_t)o[k];
-                    ((uint2*)(y + row * d))[c] = pk.u;
+                    *(uint2*)dst = pk.u;
                 }
             }
         }
@@ -178,12 +180,13 @@ inline int stream_grid(long n, int block) { return (int)(n / block + 1 < 4096 ? 
 }  // namespace
 
 int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* gamma, const float* beta, long rows,
-                 int d, hipStream_t s)
+                 int d, hipStream_t s, int packed)
 {
     UW_REQUIRE(d % 4 == 0 && d <= 2048 && rows > 0, "layernorm: d=%d rows=%ld unsupported", d, rows);
+    UW_REQUIRE(!packed || d % (dtype == UW_F32 ? 16 : 32) == 0, "layernorm: packed output needs d=%d to be a multiple of 64 bytes", d);
     const dim3 grid((unsigned)((rows + 3) / 4));
-    if (dtype == UW_F32) hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, y32, gamma, beta, rows, d);
-    else hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, y32, gamma, beta, rows, d);
+    if (dtype == UW_F32) hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, y32, gamma, beta, rows, d, packed);
+    else hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, y32, gamma, beta, rows, d, packed);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }

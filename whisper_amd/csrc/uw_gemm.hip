@@ -330,44 +330,60 @@ template <typename T, typename TC> int launch_big(const GemmParams& p, hipStream
 constexpr int SK_WAVES = 8;
 constexpr int SK_ROUND = 2;   // K-steps per register buffer; two buffers are in flight
 
-template <typename T, typename TC, int MT>
+template <typename T, typename TC, int MT, int NT, bool PACKED>
 __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int E = 16 / (int)sizeof(T);
     constexpr int KS = 4 * E;                 // K elements per step (one MFMA chunk group)
-    f32x4* part = (f32x4*)smem;               // [SK_WAVES][MT][64]
+    f32x4* part = (f32x4*)smem;               // [SK_WAVES][MT * NT][64]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: K offsets stay scalar
     const int fr = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * (NT * 16), m0 = blockIdx.y * (MT * 16);
     const int steps_total = p.K / KS;
     const int s_begin = (steps_total * wave) / SK_WAVES, s_end = (steps_total * (wave + 1)) / SK_WAVES;
     // buffer descriptors keep the loads in the global address space with 32-bit per-lane offsets; the K
     // position of a round is a scalar offset and the step inside the round an immediate
     constexpr int ES = (int)sizeof(T);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((long)p.N * p.ldb * ES), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((long)p.M * p.lda * ES), 0x00020000);
-    const int woff = (int)(((long)min(n0 + fr, p.N - 1) * p.ldb + fg * E) * ES);
-    int aoff[MT];
+    // bytes from one K-step to the next: 64 along a row, or one 1 KiB block in the fragment-major layout
+    constexpr int STEP_BYTES = PACKED ? 1024 : KS * ES;
+    const long w_bytes = PACKED ? (long)((p.N + 15) & ~15) * p.K * ES : (long)p.N * p.ldb * ES;
+    const long a_bytes = PACKED ? (long)((p.M + 15) & ~15) * p.K * ES : (long)p.M * p.lda * ES;
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)a_bytes, 0x00020000);
+    int woff[NT], aoff[MT];
+    if constexpr (PACKED) {
+        const int n_blocks = (p.N + 15) >> 4, m_blocks = (p.M + 15) >> 4;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) aoff[mt] = (int)(((long)min(mt * 16 + fr, p.M - 1) * p.lda + fg * E) * ES);
+        for (int nt = 0; nt < NT; ++nt) woff[nt] = min((n0 >> 4) + nt, n_blocks - 1) * steps_total * 1024 + lane * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aoff[mt] = min((m0 >> 4) + mt, m_blocks - 1) * steps_total * 1024 + lane * 16;
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) woff[nt] = (int)(((long)min(n0 + nt * 16 + fr, p.N - 1) * p.ldb + fg * E) * ES);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aoff[mt] = (int)(((long)min(m0 + mt * 16 + fr, p.M - 1) * p.lda + fg * E) * ES);
+    }
 
-    f32x4 acc[MT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto ld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) -> uint4 {
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     };
     // Rounds of SK_ROUND K-steps, double-buffered in registers: the loads of round r+1 are issued before the
     // MFMAs of round r, so a wave pays the memory latency once, not once per round.
-    uint4 wv[2][SK_ROUND], av[2][SK_ROUND][MT];
+    uint4 wv[2][SK_ROUND][NT], av[2][SK_ROUND][MT];
     auto load_round = [&](int buf, int s) {
 #pragma unroll
         for (int r = 0; r < SK_ROUND; ++r) {
-            const int koff = min(s + r, s_end - 1) * KS * ES;   // steps past the end re-read the last one (unused)
-            wv[buf][r] = ld(rsW, woff, koff);
+            const int koff = min(s + r, s_end - 1) * STEP_BYTES;   // steps past the end re-read the last one (unused)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wv[buf][r][nt] = ld(rsW, woff[nt], koff);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) av[buf][r][mt] = ld(rsA, aoff[mt], koff);
         }
@@ -377,7 +393,9 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
         for (int r = 0; r < SK_ROUND; ++r) {
             if (s + r < s_end) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) mma16<T>(wv[buf][r], av[buf][r][mt], acc[mt]);
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) mma16<T>(wv[buf][r][nt], av[buf][r][mt], acc[mt][nt]);
             }
         }
     };
@@ -397,52 +415,74 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
         }
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) part[(wave * MT + mt) * 64 + lane] = acc[mt];
-    __syncthreads();
-    // wave w < MT finishes row tile w
-    const int mt = wave;
-    const int m = mt * 16 + fr, n = n0 + fg * 4;
-    if (mt >= MT || m >= p.M || n >= p.N) return;
-    f32x4 t = part[mt * 64 + lane];
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int w = 1; w < SK_WAVES; ++w) t += part[(w * MT + mt) * 64 + lane];
+        for (int nt = 0; nt < NT; ++nt) part[(wave * MT * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
+    __syncthreads();
+    // the MT * NT output tiles are dealt over the waves; each sums the 8 partials of its tiles in wave order
     TC* __restrict__ C = (TC*)p.C;
     const float* __restrict__ R = p.residual;
-    const bool vec_ok = ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0) && (n + 3 < p.N);
-    float v[4] = {t[0], t[1], t[2], t[3]};
+    for (int tile = wave; tile < MT * NT; tile += SK_WAVES) {
+        const int mt = tile / NT, nt = tile % NT;
+        const int m = m0 + mt * 16 + fr, n = n0 + nt * 16 + fg * 4;
+        if (m >= p.M || n >= p.N) continue;
+        f32x4 t = part[tile * 64 + lane];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (p.bias_mode == 1) v[r] += (n + r < p.N) ? p.bias[n + r] : 0.f;
-        else if (p.bias_mode == 2) v[r] += p.bias[m];
-        if (p.act == 1) v[r] = gelu_erf(v[r]);
-    }
-    if (vec_ok) {
-        if (R) {
-            const f32x4 rv = *(const f32x4*)(R + (long)m * p.ldr + n);
-            v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
-        }
-        if constexpr (sizeof(TC) == 4) {
-            *(f32x4*)((float*)C + c_off(p, m, n)) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-            union { bf16_t h[4]; uint2 u; } pk;
-            pk.h[0] = (bf16_t)v[0]; pk.h[1] = (bf16_t)v[1]; pk.h[2] = (bf16_t)v[2]; pk.h[3] = (bf16_t)v[3];
-            *(uint2*)((bf16_t*)C + c_off(p, m, n)) = pk.u;
-        }
-    } else {
+        for (int w = 1; w < SK_WAVES; ++w) t += part[(w * MT * NT + tile) * 64 + lane];
+        const bool vec_ok = ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0) && (n + 3 < p.N);
+        float v[4] = {t[0], t[1], t[2], t[3]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (n + r >= p.N) break;
-            float x = v[r];
-            if (R) x += R[(long)m * p.ldr + n + r];
-            C[c_off(p, m, n) + r] = from_f32<TC>(x);
+            if (p.bias_mode == 1) v[r] += (n + r < p.N) ? p.bias[n + r] : 0.f;
+            else if (p.bias_mode == 2) v[r] += p.bias[m];
+            if (p.act == 1) v[r] = gelu_erf(v[r]);
+        }
+        if (vec_ok) {
+            if (R) {
+                const f32x4 rv = *(const f32x4*)(R + (long)m * p.ldr + n);
+                v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+            }
+            const long at = p.c_packed ? frag_elem_offset<TC>(m, n, p.N) : c_off(p, m, n);
+            if constexpr (sizeof(TC) == 4) {
+                *(f32x4*)((float*)C + at) = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                union { bf16_t h[4]; uint2 u; } pk;
+                pk.h[0] = (bf16_t)v[0]; pk.h[1] = (bf16_t)v[1]; pk.h[2] = (bf16_t)v[2]; pk.h[3] = (bf16_t)v[3];
+                *(uint2*)((bf16_t*)C + at) = pk.u;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (n + r >= p.N) break;
+                float x = v[r];
+                if (R) x += R[(long)m * p.ldr + n + r];
+                C[c_off(p, m, n) + r] = from_f32<TC>(x);
+            }
         }
     }
 }
 
-template <typename T, typename TC, int MT> int launch_skinny_mt(const GemmParams& p, hipStream_t s)
+template <typename T>
+__global__ void pack_frag_kernel(const T* __restrict__ src, long ld, T* __restrict__ dst, int R, int K)
 {
-    const size_t lds = (size_t)SK_WAVES * MT * 64 * sizeof(f32x4);
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT>), dim3((p.N + 15) / 16), dim3(64 * SK_WAVES), lds, s, p);
+    constexpr int E = 16 / (int)sizeof(T);
+    const int chunks = K / E;
+    const long n = (long)((R + 15) & ~15) * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / chunks;
+        const int c = (int)(i % chunks);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < R) v = *(const uint4*)(src + r * ld + c * E);
+        *(uint4*)(dst + frag_elem_offset<T>(r, c * E, K)) = v;
+    }
+}
+
+template <typename T, typename TC, int MT, int NT> int launch_skinny_mt(const GemmParams& p, hipStream_t s)
+{
+    const size_t lds = (size_t)SK_WAVES * MT * NT * 64 * sizeof(f32x4);
+    const dim3 grid((p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
+    if (p.ab_packed) hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT, NT, true>), grid, dim3(64 * SK_WAVES), lds, s, p);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT, NT, false>), grid, dim3(64 * SK_WAVES), lds, s, p);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }
@@ -452,15 +492,19 @@ template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStr
     constexpr int KS = 64 / (int)sizeof(T);
     UW_REQUIRE(p.M > 0 && p.M <= 128 && p.N > 0 && p.K > 0 && p.batch == 1, "skinny gemm: M=%d outside 1..128", p.M);
     UW_REQUIRE(p.K % KS == 0, "skinny gemm: K=%d must be a multiple of %d", p.K, KS);
-    UW_REQUIRE((p.lda * sizeof(T)) % 16 == 0 && (p.ldb * sizeof(T)) % 16 == 0 && ((uintptr_t)p.A % 16) == 0 &&
-                   ((uintptr_t)p.B % 16) == 0,
+    UW_REQUIRE(((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0 &&
+                   (p.ab_packed || ((p.lda * sizeof(T)) % 16 == 0 && (p.ldb * sizeof(T)) % 16 == 0)),
                "skinny gemm: operand rows must be 16-byte aligned");
-    UW_REQUIRE((long)p.N * p.ldb * (long)sizeof(T) < (1l << 31) && (long)p.M * p.lda * (long)sizeof(T) < (1l << 31),
-               "skinny gemm: operands must be under 2 GiB");
-    if (p.M <= 16) return launch_skinny_mt<T, TC, 1>(p, s);
-    if (p.M <= 32) return launch_skinny_mt<T, TC, 2>(p, s);
-    if (p.M <= 64) return launch_skinny_mt<T, TC, 4>(p, s);
-    return launch_skinny_mt<T, TC, 8>(p, s);
+    const long w_rows = p.ab_packed ? (long)((p.N + 15) & ~15) * p.K : (long)p.N * p.ldb;
+    const long a_rows = p.ab_packed ? (long)((p.M + 15) & ~15) * p.K : (long)p.M * p.lda;
+    UW_REQUIRE(w_rows * (long)sizeof(T) < (1l << 31) && a_rows * (long)sizeof(T) < (1l << 31), "skinny gemm: operands must be under 2 GiB");
+    UW_REQUIRE(!p.c_packed || (sizeof(TC) == sizeof(T) && p.N % KS == 0 && !p.c_group),
+               "skinny gemm: packed output needs the compute dtype and N=%d a multiple of %d", p.N, KS);
+    // 16 x 16 output tiles per workgroup: few rows per workgroup keep its activation traffic small; wide N takes
+    // more tiles per workgroup so the grid stays near one workgroup per CU
+    if (p.M <= 16) return p.N >= 2048 ? launch_skinny_mt<T, TC, 1, 2>(p, s) : launch_skinny_mt<T, TC, 1, 1>(p, s);
+    if (p.N >= 2048 && p.M > 32) return launch_skinny_mt<T, TC, 4, 2>(p, s);
+    return launch_skinny_mt<T, TC, 2, 1>(p, s);
 }
 
 }  // namespace
@@ -470,6 +514,18 @@ int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
     if (dtype == UW_F32) return launch_skinny<float, float>(p, s);
     if (out_f32) return launch_skinny<bf16_t, float>(p, s);
     return launch_skinny<bf16_t, bf16_t>(p, s);
+}
+
+int uw_pack_frag(int dtype, const void* src, long ld, void* dst, int R, int K, hipStream_t s)
+{
+    const int E = dtype == UW_F32 ? 4 : 8;
+    UW_REQUIRE(src && dst && R > 0 && K > 0 && K % (4 * E) == 0 && (ld * (16 / E)) % 16 == 0, "pack_frag: bad shape R=%d K=%d", R, K);
+    const long n = (long)((R + 15) & ~15) * (K / E);
+    const int grid = (int)std::min<long>((n + 255) / 256, 65535);
+    if (dtype == UW_F32) hipLaunchKernelGGL(pack_frag_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, ld, (float*)dst, R, K);
+    else hipLaunchKernelGGL(pack_frag_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)src, ld, (bf16_t*)dst, R, K);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
 }
 
 int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s)

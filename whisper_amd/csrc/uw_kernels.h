@@ -20,18 +20,24 @@ struct GemmParams {
     int M = 0, N = 0, K = 0, batch = 1;
     int bias_mode = 0;  // 0 none, 1 bias[n], 2 bias[m]
     int act = 0;        // 0 none, 1 GELU(erf)
+    int ab_packed = 0, c_packed = 0;  // fragment-major operands / output (skinny form only)
     long c_group = 0;   // 0: C[m][n] at m*ldc + n.  Else columns are stored in groups of 64 (one attention head):
                         // C[m][n] at (n / 64) * c_group + m * ldc + (n % 64), ldc = 64 for a head-contiguous cache
 };
 // dtype: element type of A and B.  out_f32: C is f32 even when dtype is bf16 (always f32 for UW_F32).
 int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
-// M <= 128, batch 1: weight-streaming form for the decode step
+// M <= 128, batch 1: weight-streaming form for the decode step.  With p.ab_packed both A and B are in the
+// fragment-major layout (frag_elem_offset in uw_common.h; rows padded to 16, lda/ldb unused); with p.c_packed
+// C (compute dtype only) is written in that layout too, ready to be the next product's A.
 int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
+// row-major [R][K] (row stride ld) -> fragment-major, rows zero-padded to a multiple of 16
+int uw_pack_frag(int dtype, const void* src, long ld, void* dst, int R, int K, hipStream_t s);
 
 // ---- uw_elementwise.hip -----------------------------------------------------------------------
 // y[r][:] = LayerNorm(x[r][:]) * gamma + beta, eps 1e-5.  y in dtype; y32 (optional) also gets f32.
+// packed: y is written fragment-major (frag_elem_offset), the A operand of the decode-step GEMMs
 int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* gamma, const float* beta, long rows,
-                 int d, hipStream_t s);
+                 int d, hipStream_t s, int packed = 0);
 // dst (dtype) = src (f32) * scale, n elements
 int uw_convert(int dtype, const float* src, void* dst, long n, float scale, hipStream_t s);
 // conv weight [co][ci][3] f32 -> [co][kpad] dtype with k index = tap * ci_count + ci, zero padded to kpad
@@ -84,6 +90,7 @@ struct SelfDecodeParams {
     void* kcache = nullptr;     // this layer's cache: element (b, h, r, e) at b*cache_sB + h*cache_sH + r*ld_cache + e
     void* vcache = nullptr;
     void* out = nullptr;        // [B][d]
+    int out_packed = 0;         // out in the fragment-major layout
     const int32_t* pos = nullptr;     // per window position of the current token
     const int32_t* active = nullptr;  // per window: 0 = finished (skip)
     long ld_cache = 0;          // row stride of the caches (elements)
@@ -97,6 +104,7 @@ struct CrossDecodeParams {
     const void* K = nullptr;   // this layer: element (b, h, r, e) at b*kv_sB + h*kv_sH + r*ld_kv + e
     const void* V = nullptr;
     void* out = nullptr;       // [B][d]
+    int out_packed = 0;        // out in the fragment-major layout
     float* rows = nullptr;     // attention rows [B][n_sel][n_rows_max][S] or null
     long rows_sB = 0, rows_sSel = 0;
     const int32_t* row_index = nullptr;  // per window: row slot to write (text tokens emitted so far)
