@@ -6,8 +6,8 @@
 
 namespace {
 
-// one wave per row; d <= 2048, d % 4 == 0
-template <typename T>
+// one wave per row; NI = float4 groups per lane (d <= 256 * NI), d % 4 == 0
+template <typename T, int NI>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, T* __restrict__ y,
                                                         float* __restrict__ y32, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, long rows, int d, int packed)
@@ -17,22 +17,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int lane = threadIdx.x & 63;
     const f32x4* xr = (const f32x4*)(x + row * d);
     const int nv = d >> 2;
-    f32x4 v[8];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[NI], g[NI], bb[NI];
+    // scale and shift are requested together with the row: one memory round trip, not two
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane + i * 64;
+        const bool in = c < nv;
+        v[i] = in ? xr[c] : zero;
+        g[i] = in ? ((const f32x4*)gamma)[c] : zero;
+        bb[i] = in ? ((const f32x4*)beta)[c] : zero;
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
-            v[i] = xr[c];
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
-    }
+    for (int i = 0; i < NI; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = lane + i * 64;
-        if (c < nv) {
+    for (int i = 0; i < NI; ++i) {
+        if (lane + i * 64 < nv) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float t = v[i][k] - mean;
@@ -42,13 +45,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int c = lane + i * 64;
         if (c < nv) {
-            const f32x4 g = ((const f32x4*)gamma)[c], bb = ((const f32x4*)beta)[c];
             f32x4 o;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mean) * rstd * g[k] + bb[k];
+            for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mean) * rstd * g[i][k] + bb[i][k];
             if (y32) ((f32x4*)(y32 + row * d))[c] = o;
             if (y) {
                 // four consecutive columns never straddle a 16-byte chunk, so they stay contiguous when packed
@@ -185,8 +187,19 @@ int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* ga
     UW_REQUIRE(d % 4 == 0 && d <= 2048 && rows > 0, "layernorm: d=%d rows=%ld unsupported", d, rows);
     UW_REQUIRE(!packed || d % (dtype == UW_F32 ? 16 : 32) == 0, "layernorm: packed output needs d=%d to be a multiple of 64 bytes", d);
     const dim3 grid((unsigned)((rows + 3) / 4));
-    if (dtype == UW_F32) hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, y32, gamma, beta, rows, d, packed);
-    else hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, y32, gamma, beta, rows, d, packed);
+    const int ni = (d / 4 + 63) / 64;
+#define UW_LN_LAUNCH(NI)                                                                                                         \
+    do {                                                                                                                         \
+        if (dtype == UW_F32) hipLaunchKernelGGL((layernorm_kernel<float, NI>), grid, dim3(256), 0, s, x, (float*)y, y32, gamma, beta, rows, d, packed); \
+        else hipLaunchKernelGGL((layernorm_kernel<bf16_t, NI>), grid, dim3(256), 0, s, x, (bf16_t*)y, y32, gamma, beta, rows, d, packed);              \
+    } while (0)
+    if (ni <= 1) UW_LN_LAUNCH(1);
+    else if (ni <= 2) UW_LN_LAUNCH(2);
+    else if (ni <= 3) UW_LN_LAUNCH(3);
+    else if (ni <= 4) UW_LN_LAUNCH(4);
+    else if (ni <= 6) UW_LN_LAUNCH(6);
+    else UW_LN_LAUNCH(8);
+#undef UW_LN_LAUNCH
     UW_LAUNCH_CHECK();
     return UW_OK;
 }
