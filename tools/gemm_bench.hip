@@ -16,7 +16,7 @@ int main(int argc, char** argv)
         CK(hipMalloc(&W, (size_t)sh.N * sh.K * 2)); CK(hipMalloc(&A, (size_t)M * sh.K * 2)); CK(hipMalloc(&C, (size_t)M * sh.N * 4)); CK(hipMalloc(&bias, sh.N * 4));
         CK(hipMemset(W, 0, (size_t)sh.N * sh.K * 2)); CK(hipMemset(A, 0, (size_t)M * sh.K * 2)); CK(hipMemset(C, 0, (size_t)M * sh.N * 4)); CK(hipMemset(bias, 0, sh.N * 4));
         GemmParams p; p.A = A; p.B = W; p.C = C; p.bias = bias; p.lda = sh.K; p.ldb = sh.K; p.ldc = sh.N; p.ldr = sh.N; p.M = M; p.N = sh.N; p.K = sh.K;
-        p.bias_mode = 1; p.act = sh.act; p.residual = sh.res ? C : nullptr;
+        p.bias_mode = 1; p.act = getenv("NOACT") ? 0 : sh.act; p.residual = sh.res ? C : nullptr;
         const int iters = 5;
         for (int rep = 0; rep < 2; ++rep) {
             if (rep == 1) CK(hipEventRecord(e0, s));

@@ -176,16 +176,7 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmParams p)
     const int wr = wave >> 1, wc = wave & 1;
     const int tiles_n = (p.N + B2N - 1) / B2N;
     const int tile = xcd_contiguous_tile(blockIdx.x, gridDim.x);
-#ifdef GB_STRIP
-    // strips of GB_STRIP column tiles, rows swept inside a strip
-    const int tiles_m = (p.M + B2M - 1) / B2M;
-    const int per_strip = GB_STRIP * tiles_m;
-    const int strip = tile / per_strip, in_strip = tile % per_strip;
-    const int sw = min(GB_STRIP, tiles_n - strip * GB_STRIP);
-    const int m0 = (in_strip / sw) * B2M, n0 = (strip * GB_STRIP + in_strip % sw) * B2N;
-#else
     const int m0 = (tile / tiles_n) * B2M, n0 = (tile % tiles_n) * B2N;
-#endif
     const long bz = blockIdx.y;
     const T* __restrict__ A = (const T*)p.A + bz * p.sA;
     const T* __restrict__ B = (const T*)p.B + bz * p.sB;
@@ -227,9 +218,7 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmParams p)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#ifndef GB_NOLOAD
         if (kt + 2 < nk) stage(kt + 2, (kt + 2) % NSTAGE2);
-#endif
         const char* As = smem + (kt % NSTAGE2) * STAGE2;
         const char* Bs = As + A2_BYTES;
 #pragma unroll
@@ -249,9 +238,6 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmParams p)
     }
     // ---- epilogue: bias / activation in registers, f32 tile through LDS, coalesced residual add + store ----
     __syncthreads();
-#ifdef GB_NOSTORE
-    if (acc[0][0][0] != 12345.f) return;
-#endif
     float* ep = (float*)smem + wave * (64 * EP_PITCH);
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
@@ -312,6 +298,194 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(GemmParams p)
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large-M form for TWO co-resident workgroups per CU: same 256 x 128 tile and 8 waves, but 64-byte K rows
+// (three 24 KiB stages = 72 KiB) and at most 128 registers, so that one workgroup's epilogue (bias,
+// activation, the HBM-bound store of the tile) overlaps the other workgroup's MFMA loop.  With K = 768 a tile
+// holds only a few microseconds of MFMA work, so an epilogue that nothing overlaps costs as much as the loop.
+// LDS image: row pitch 64 bytes; the 16-byte chunk k of row r sits at position k ^ ((-(r >> 2)) & 3), which
+// spreads each 16-lane group of a ds_read_b128 over all 64 banks.
+// the output tile is written once and read by a later kernel from HBM: non-temporal store
+#define STORE16_NT(ptr, val) __builtin_nontemporal_store((val), (f32x4*)(ptr))
+constexpr int K3_ROW = 64;                                         // bytes of K per tile row and stage
+constexpr int A3_BYTES = B2M * K3_ROW, B3_BYTES = B2N * K3_ROW, STAGE3 = A3_BYTES + B3_BYTES;   // 24 KiB
+constexpr int NSTAGE3 = 3;
+
+template <typename T, typename TC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_tn_duo_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = 16 / (int)sizeof(T);
+    constexpr int KT = K3_ROW / (int)sizeof(T);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tiles_n = (p.N + B2N - 1) / B2N;
+    const int tiles_mn = tiles_n * ((p.M + B2M - 1) / B2M), total = tiles_mn * p.batch;
+    const int frow = lane & 15, fg = lane >> 4;
+    const unsigned lds_base = lds_addr_of(smem) + wave * 1024;
+    const int vt = xcd_contiguous_tile(blockIdx.x, total);
+    const long bz = vt / tiles_mn;
+    const int tile = vt % tiles_mn;
+    const int m0 = (tile / tiles_n) * B2M, n0 = (tile % tiles_n) * B2N;
+    const T* __restrict__ A = (const T*)p.A + bz * p.sA;
+    const T* __restrict__ B = (const T*)p.B + bz * p.sB;
+
+    // one DMA instruction of a wave fills 16 rows x 64 bytes; lane -> (row, position), source chunk = position ^ g(row)
+    const T* srcA[2];
+    const T* srcB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = i * 512 + tid, row = L >> 2, c = (L & 3) ^ ((-(row >> 2)) & 3);
+        srcA[i] = A + (long)min(m0 + row, p.M - 1) * p.lda + c * E;
+    }
+    {
+        const int row = tid >> 2, c = (tid & 3) ^ ((-(row >> 2)) & 3);
+        srcB = B + (long)min(n0 + row, p.N - 1) * p.ldb + c * E;
+    }
+    auto stage = [&](int kt, int st) {
+        const unsigned a_dst = lds_base + st * STAGE3, b_dst = a_dst + A3_BYTES;
+        glds16(srcA[0] + (long)kt * KT, a_dst);
+        glds16(srcA[1] + (long)kt * KT, a_dst + 8192);
+        glds16(srcB + (long)kt * KT, b_dst);
+    };
+
+    // the accumulators start at bias + residual: those loads ride behind the first K-stage instead of opening the
+    // epilogue (a tile's residual is read before any workgroup writes that tile, so C may alias the residual)
+    const float* __restrict__ R = p.residual ? p.residual + bz * p.sR : nullptr;
+    const bool r_vec = (p.ldr & 3) == 0;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wr * 64 + i * 16 + frow;
+        const float bias_m = (p.bias_mode == 2 && m < p.M) ? p.bias[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wc * 64 + j * 16 + fg * 4;
+            if (p.bias_mode == 1) {
+                if (n + 3 < p.N) acc[i][j] = *(const f32x4*)(p.bias + n);
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = (n + r < p.N) ? p.bias[n + r] : 0.f;
+            } else {
+                acc[i][j] = f32x4{bias_m, bias_m, bias_m, bias_m};
+            }
+            if (R && m < p.M) {
+                if (r_vec && n + 3 < p.N) acc[i][j] += *(const f32x4*)(R + (long)m * p.ldr + n);
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += (n + r < p.N) ? R[(long)m * p.ldr + n + r] : 0.f;
+            }
+        }
+    }
+
+    const int nk = p.K / KT;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's three DMA pieces of tile kt are older than the three of tile kt+1
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) stage(kt + 2, (kt + 2) % NSTAGE3);
+        const char* As = smem + (kt % NSTAGE3) * STAGE3;
+        const char* Bs = As + A3_BYTES;
+        uint4 af[4], bf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            // rows t*16 + frow of a 64-row block: (row >> 2) & 3 == (frow >> 2) & 3
+            const int pos = (fg ^ ((-(frow >> 2)) & 3)) << 4;
+            af[t] = *(const uint4*)(As + (wr * 64 + t * 16 + frow) * K3_ROW + pos);
+            bf[t] = *(const uint4*)(Bs + (wc * 64 + t * 16 + frow) * K3_ROW + pos);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) mma16<T>(bf[tn], af[tm], acc[tm][tn]);
+    }
+    // ---- epilogue: two halves of 32 rows per wave through the idle ring (69.6 KiB of its 72) ----
+    __syncthreads();
+    float* ep = (float*)smem + wave * (32 * EP_PITCH);
+    TC* __restrict__ C = (TC*)p.C + bz * p.sC;
+    const int nbase = n0 + wc * 64;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int tm = half * 2 + t2;
+            const int ml = t2 * 16 + frow;
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                const int nl = tn * 16 + fg * 4;
+                f32x4 v = acc[tm][tn];
+                if (p.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+                *(f32x4*)(ep + ml * EP_PITCH + nl) = v;
+            }
+        }
+        // the wave reads back only what it wrote: LDS operations of one wave are ordered, no barrier needed
+        const int mbase = m0 + wr * 64 + half * 32;
+        if constexpr (sizeof(TC) == 4) {
+            const bool vec_ok = (p.ldc & 3) == 0;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int ml = it * 4 + (lane >> 4), nl = (lane & 15) * 4;
+                const int m = mbase + ml, n = nbase + nl;
+                if (m >= p.M || n >= p.N) continue;
+                const f32x4 v = *(const f32x4*)(ep + ml * EP_PITCH + nl);
+                if (vec_ok && n + 3 < p.N) {
+                    STORE16_NT((float*)C + c_off(p, m, n), v);
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) ((float*)C)[c_off(p, m, n) + r] = v[r];
+                }
+            }
+        } else {
+            const bool vec_ok = ((p.ldc & 7) == 0) && (((uintptr_t)C & 15) == 0);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int ml = it * 8 + (lane >> 3), nl = (lane & 7) * 8;
+                const int m = mbase + ml, n = nbase + nl;
+                if (m >= p.M || n >= p.N) continue;
+                const f32x4 v0 = *(const f32x4*)(ep + ml * EP_PITCH + nl), v1 = *(const f32x4*)(ep + ml * EP_PITCH + nl + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (vec_ok && n + 7 < p.N) {
+                    union { bf16_t h[8]; uint4 u; } pk;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) pk.h[r] = (bf16_t)v[r];
+                    STORE16_NT((bf16_t*)C + c_off(p, m, n), __builtin_bit_cast(f32x4, pk.u));
+                } else {
+                    for (int r = 0; r < 8 && n + r < p.N; ++r) C[c_off(p, m, n) + r] = from_f32<TC>(v[r]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename TC> int launch_duo(const GemmParams& p, hipStream_t s)
+{
+    constexpr int KT = K3_ROW / (int)sizeof(T);
+    UW_REQUIRE(p.K % KT == 0, "gemm: K=%d must be a multiple of %d", p.K, KT);
+    UW_REQUIRE((p.lda * sizeof(T)) % 16 == 0 && (p.ldb * sizeof(T)) % 16 == 0 && (p.sA * sizeof(T)) % 16 == 0 &&
+                   (p.sB * sizeof(T)) % 16 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0,
+               "gemm: operand rows must be 16-byte aligned");
+    const long tiles = (long)ceil_div(p.M, B2M) * ceil_div(p.N, B2N);
+    UW_REQUIRE(tiles * p.batch < (1l << 31), "gemm: too many tiles");
+    const size_t lds = (size_t)NSTAGE3 * STAGE3;
+    static bool attr_set = false;
+    if (!attr_set) {
+        UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_duo_kernel<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const long total = tiles * p.batch;
+    const unsigned grid = (unsigned)total;
+    hipLaunchKernelGGL((gemm_tn_duo_kernel<T, TC>), dim3(grid), dim3(512), lds, s, p);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
 }
 
 template <typename T, typename TC> int launch_big(const GemmParams& p, hipStream_t s)
@@ -544,7 +718,14 @@ int uw_pack_frag(int dtype, const void* src, long ld, void* dst, int R, int K, h
 
 int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
 {
-    static const bool use_big = !(getenv("UW_GEMM_BIG") && atoi(getenv("UW_GEMM_BIG")) == 0);
+    static const int big_mode = getenv("UW_GEMM_BIG") ? atoi(getenv("UW_GEMM_BIG")) : 2;   // 0: 128x128 only, 1: one WG/CU, 2: two WGs/CU
+    const bool use_big = big_mode != 0;
+    // the two-workgroup kernel folds the residual into the accumulator start, which is only right without an activation
+    if (big_mode == 2 && p.M >= 512 && !(p.act && p.residual)) {
+        if (dtype == UW_F32) return launch_duo<float, float>(p, s);
+        if (out_f32) return launch_duo<bf16_t, float>(p, s);
+        return launch_duo<bf16_t, bf16_t>(p, s);
+    }
     if (use_big && p.M >= 512) {   // enough rows to fill 256-row tiles
         if (dtype == UW_F32) return launch_big<float, float>(p, s);
         if (out_f32) return launch_big<bf16_t, float>(p, s);
