@@ -554,6 +554,34 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
         for (int mt = 0; mt < MT; ++mt) aoff[mt] = (int)(((long)min(m0 + mt * 16 + fr, p.M - 1) * p.lda + fg * E) * ES);
     }
 
+    // wave w finishes output tile w after the reduction; its bias and residual are requested now so that they
+    // arrive during the K loop instead of stalling the epilogue
+    static_assert(MT * NT <= SK_WAVES, "one output tile per wave");
+    TC* __restrict__ C = (TC*)p.C;
+    const float* __restrict__ R = p.residual;
+    const int e_mt = wave / NT, e_nt = wave % NT;
+    const int e_m = m0 + e_mt * 16 + fr, e_n = n0 + e_nt * 16 + fg * 4;
+    const bool e_live = wave < MT * NT && e_m < p.M && e_n < p.N;
+    const bool vec_ok = ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0) && (e_n + 3 < p.N);
+    f32x4 e_bias = {0.f, 0.f, 0.f, 0.f}, e_res = {0.f, 0.f, 0.f, 0.f};
+    if (e_live) {
+        if (p.bias_mode == 1) {
+            if (e_n + 3 < p.N) e_bias = *(const f32x4*)(p.bias + e_n);
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e_bias[r] = (e_n + r < p.N) ? p.bias[e_n + r] : 0.f;
+        } else if (p.bias_mode == 2) {
+            const float b = p.bias[e_m];
+            e_bias = f32x4{b, b, b, b};
+        }
+        if (R) {
+            if (vec_ok) e_res = *(const f32x4*)(R + (long)e_m * p.ldr + e_n);
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e_res[r] = (e_n + r < p.N) ? R[(long)e_m * p.ldr + e_n + r] : 0.f;
+        }
+    }
+
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -607,45 +635,31 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) part[(wave * MT * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
     __syncthreads();
-    // the MT * NT output tiles are dealt over the waves; each sums the 8 partials of its tiles in wave order
-    TC* __restrict__ C = (TC*)p.C;
-    const float* __restrict__ R = p.residual;
-    for (int tile = wave; tile < MT * NT; tile += SK_WAVES) {
-        const int mt = tile / NT, nt = tile % NT;
-        const int m = m0 + mt * 16 + fr, n = n0 + nt * 16 + fg * 4;
-        if (m >= p.M || n >= p.N) continue;
-        f32x4 t = part[tile * 64 + lane];
+    // wave w < MT * NT sums the 8 partials of tile w in wave order (run-to-run identical)
+    if (!e_live) return;
+    f32x4 t = part[wave * 64 + lane];
 #pragma unroll
-        for (int w = 1; w < SK_WAVES; ++w) t += part[(w * MT * NT + tile) * 64 + lane];
-        const bool vec_ok = ((p.ldc & 3) == 0) && (!R || (p.ldr & 3) == 0) && (n + 3 < p.N);
-        float v[4] = {t[0], t[1], t[2], t[3]};
+    for (int w = 1; w < SK_WAVES; ++w) t += part[(w * MT * NT + wave) * 64 + lane];
+    f32x4 v = t + e_bias;
+    if (p.act == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    }
+    v += e_res;
+    if (vec_ok) {
+        const long at = p.c_packed ? frag_elem_offset<TC>(e_m, e_n, p.N) : c_off(p, e_m, e_n);
+        if constexpr (sizeof(TC) == 4) {
+            *(f32x4*)((float*)C + at) = v;
+        } else {
+            union { bf16_t h[4]; uint2 u; } pk;
+            pk.h[0] = (bf16_t)v[0]; pk.h[1] = (bf16_t)v[1]; pk.h[2] = (bf16_t)v[2]; pk.h[3] = (bf16_t)v[3];
+            *(uint2*)((bf16_t*)C + at) = pk.u;
+        }
+    } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (p.bias_mode == 1) v[r] += (n + r < p.N) ? p.bias[n + r] : 0.f;
-            else if (p.bias_mode == 2) v[r] += p.bias[m];
-            if (p.act == 1) v[r] = gelu_erf(v[r]);
-        }
-        if (vec_ok) {
-            if (R) {
-                const f32x4 rv = *(const f32x4*)(R + (long)m * p.ldr + n);
-                v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
-            }
-            const long at = p.c_packed ? frag_elem_offset<TC>(m, n, p.N) : c_off(p, m, n);
-            if constexpr (sizeof(TC) == 4) {
-                *(f32x4*)((float*)C + at) = f32x4{v[0], v[1], v[2], v[3]};
-            } else {
-                union { bf16_t h[4]; uint2 u; } pk;
-                pk.h[0] = (bf16_t)v[0]; pk.h[1] = (bf16_t)v[1]; pk.h[2] = (bf16_t)v[2]; pk.h[3] = (bf16_t)v[3];
-                *(uint2*)((bf16_t*)C + at) = pk.u;
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (n + r >= p.N) break;
-                float x = v[r];
-                if (R) x += R[(long)m * p.ldr + n + r];
-                C[c_off(p, m, n) + r] = from_f32<TC>(x);
-            }
+            if (e_n + r >= p.N) break;
+            C[c_off(p, e_m, e_n) + r] = from_f32<TC>(v[r]);
         }
     }
 }
