@@ -48,7 +48,7 @@ template <> __device__ __forceinline__ uint4 pack_p<bf16_t>(const f32x16& p, int
 }
 
 template <typename T, bool PROBS>
-__global__ __launch_bounds__(256) void attention_kernel(AttnParams p, ProbParams pp)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attention_kernel(AttnParams p, ProbParams pp)
 {
     using L = Lay<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,10 +141,6 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p, ProbParams
                 for (int r = 0; r < 16; ++r)
                     if (key0 + key_of(sub, r, hl) > lim) st[sub][r] = -INFINITY;
         }
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[sub][r] *= LOG2E;
     };
 
     constexpr int PASSES = PROBS ? 2 : 1;
@@ -172,32 +168,35 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p, ProbParams
                             const int key = j * 64 + key_of(sub, g * 8, hl);
 #pragma unroll
                             for (int k = 0; k < 8; ++k)
-                                if (key + k < Sk) prow[key + k] = __builtin_amdgcn_exp2f(st[sub][g * 8 + k] - m_run) * inv_l;
+                                if (key + k < Sk) prow[key + k] = __builtin_amdgcn_exp2f((st[sub][g * 8 + k] - m_run) * LOG2E) * inv_l;
                         }
                 }
                 continue;
             }
-            float mx = st[0][0];
+            // running maximum in raw score units; exponentials as exp2(s * log2e - m * log2e): one FMA per score
+            float mx = fmaxf(st[0][0], st[1][0]);
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
+            for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, st[0][r]), st[1][r]);   // folds to v_max3_f32
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);  // first tile: exp2(-inf) = 0
+            const float neg_m = -m_new * LOG2E;
             float rs = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    st[sub][r] = __builtin_amdgcn_exp2f(st[sub][r] - m_new);
+                    st[sub][r] = __builtin_amdgcn_exp2f(fmaf(st[sub][r], LOG2E, neg_m));
                     rs += st[sub][r];
                 }
             l_run = l_run * alpha + rs;
+            const bool rescale = __any(m_new != m_run);   // wave-uniform: most tiles leave every maximum unchanged
             m_run = m_new;
             if constexpr (!PROBS) {
+                if (rescale) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+                    for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
+                }
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
