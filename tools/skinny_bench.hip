@@ -16,10 +16,12 @@ int main(int argc, char** argv)
         const size_t wbytes = (size_t)sh.N * sh.K * 2;
         const int copies = (int)((600u << 20) / wbytes) + 1;
         char *W, *A; float *C, *bias;
-        CK(hipMalloc(&W, wbytes * copies)); CK(hipMalloc(&A, (size_t)M * sh.K * 2)); CK(hipMalloc(&C, (size_t)M * sh.N * 4)); CK(hipMalloc(&bias, sh.N * 4));
-        CK(hipMemset(W, 0, wbytes * copies)); CK(hipMemset(A, 0, (size_t)M * sh.K * 2)); CK(hipMemset(C, 0, (size_t)M * sh.N * 4)); CK(hipMemset(bias, 0, sh.N * 4));
+        CK(hipMalloc(&W, wbytes * copies)); CK(hipMalloc(&A, (size_t)M * sh.K * 4)); CK(hipMalloc(&C, (size_t)M * sh.N * 4)); CK(hipMalloc(&bias, sh.N * 4));
+        CK(hipMemset(W, 0, wbytes * copies)); CK(hipMemset(A, 0, (size_t)M * sh.K * 4)); CK(hipMemset(C, 0, (size_t)M * sh.N * 4)); CK(hipMemset(bias, 0, sh.N * 4));
         GemmParams p; p.A = A; p.C = C; p.bias = bias; p.lda = sh.K; p.ldb = sh.K; p.ldc = sh.N; p.ldr = sh.N; p.M = M; p.N = sh.N; p.K = sh.K;
-        p.bias_mode = 1; p.act = sh.act; p.ab_packed = getenv("PACKED") ? 1 : 0; p.c_packed = (p.ab_packed && sh.act) ? 1 : 0; p.residual = sh.res ? C : nullptr;
+        p.bias_mode = 1; p.act = sh.act; p.ab_packed = getenv("PACKED") ? 1 : 0; p.c_packed = (p.ab_packed && sh.act) ? 1 : 0;
+        if (getenv("LN") && !sh.res) { p.ln_fused = 1; p.wsum = bias; p.ab_packed = 1; }
+        if (p.ab_packed && sh.res) p.c_xlayout = 1; p.residual = sh.res ? C : nullptr;
         const int iters = 400;
         for (int rep = 0; rep < 2; ++rep) {
             if (rep == 1) CK(hipEventRecord(e0, s));

@@ -32,11 +32,15 @@ struct AttnW {            // one attention block
     float* bo = nullptr;
     float *ln_g = nullptr, *ln_b = nullptr;
     void *wqkv_p = nullptr, *wq_p = nullptr, *wo_p = nullptr;   // fragment-major copies for the decode step
+    float *bln = nullptr, *wsum = nullptr;                        // LayerNorm folded into wqkv_p / wq_p: bias and row sums
+    const float *src_wq = nullptr, *src_wk = nullptr, *src_wv = nullptr, *src_bq = nullptr, *src_bv = nullptr;   // caller's f32 tensors (valid during load)
 };
 struct LayerW {
     AttnW self, cross;
     void *w1 = nullptr, *w2 = nullptr;
     void *w1_p = nullptr, *w2_p = nullptr;
+    float *b1ln = nullptr, *w1sum = nullptr;
+    const float *src_w1 = nullptr, *src_b1 = nullptr;
     float *b1 = nullptr, *b2 = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
 };
 
@@ -139,6 +143,7 @@ int load_attn(uw_ctx* c, Cursor& cur, AttnW& a, int kind /*0 enc self, 1 dec sel
     const float *wq = cur.next(), *bq = cur.next(), *wk = cur.next(), *wv = cur.next(), *bv = cur.next(), *wo = cur.next(),
                 *bo = cur.next(), *lg = cur.next(), *lb = cur.next();
     UW_REQUIRE(wq && bq && wk && wv && bv && wo && bo && lg && lb, "attention weights missing");
+    a.src_wq = wq; a.src_wk = wk; a.src_wv = wv; a.src_bq = bq; a.src_bv = bv;
     if (kind == 1) {
         ALLOC(a.wqkv, 3 * d * d * c->es, false);
         ALLOC(a.bqkv, 3 * d * 4, true);
@@ -189,6 +194,7 @@ int load_mlp(uw_ctx* c, Cursor& cur, LayerW& l)
     const long d = c->d, f = 4 * d;
     const float *w1 = cur.next(), *b1 = cur.next(), *w2 = cur.next(), *b2 = cur.next(), *lg = cur.next(), *lb = cur.next();
     UW_REQUIRE(w1 && b1 && w2 && b2 && lg && lb, "mlp weights missing");
+    l.src_w1 = w1; l.src_b1 = b1;
     ALLOC(l.w1, f * d * c->es, false);
     ALLOC(l.b1, f * 4, false);
     ALLOC(l.w2, d * f * c->es, false);
@@ -251,21 +257,42 @@ int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
         RUN(load_attn(c, cur, l.cross, 2));
         RUN(load_mlp(c, cur, l));
     }
-    // the KV-cached step reads its weights as whole MFMA operand blocks: second, fragment-major copy
-    for (auto& l : c->dec) {
+    // the KV-cached step reads its weights as whole MFMA operand blocks: second, fragment-major copy.  The three
+    // products that follow a LayerNorm (q|k|v, cross q, fc1) get the LayerNorm folded in: scale into the weights,
+    // shift into the bias, plus the row sums the kernel needs for the mean.
+    {
         const long f = 4 * d;
-        ALLOC(l.self.wqkv_p, 3 * d * d * c->es, false);
-        ALLOC(l.self.wo_p, d * d * c->es, false);
-        ALLOC(l.cross.wq_p, d * d * c->es, false);
-        ALLOC(l.cross.wo_p, d * d * c->es, false);
-        ALLOC(l.w1_p, f * d * c->es, false);
-        ALLOC(l.w2_p, d * f * c->es, false);
-        RUN(uw_pack_frag(c->dt, l.self.wqkv, d, l.self.wqkv_p, (int)(3 * d), (int)d, 0));
-        RUN(uw_pack_frag(c->dt, l.self.wo, d, l.self.wo_p, (int)d, (int)d, 0));
-        RUN(uw_pack_frag(c->dt, l.cross.wq, d, l.cross.wq_p, (int)d, (int)d, 0));
-        RUN(uw_pack_frag(c->dt, l.cross.wo, d, l.cross.wo_p, (int)d, (int)d, 0));
-        RUN(uw_pack_frag(c->dt, l.w1, d, l.w1_p, (int)f, (int)d, 0));
-        RUN(uw_pack_frag(c->dt, l.w2, f, l.w2_p, (int)d, (int)f, 0));
+        void* tmp = nullptr;
+        UW_HIP_CHECK(hipMalloc(&tmp, (size_t)f * d * c->es));
+        for (auto& l : c->dec) {
+            ALLOC(l.self.wqkv_p, 3 * d * d * c->es, false);
+            ALLOC(l.self.wo_p, d * d * c->es, false);
+            ALLOC(l.cross.wq_p, d * d * c->es, false);
+            ALLOC(l.cross.wo_p, d * d * c->es, false);
+            ALLOC(l.w1_p, f * d * c->es, false);
+            ALLOC(l.w2_p, d * f * c->es, false);
+            ALLOC(l.self.bln, 3 * d * 4, false);
+            ALLOC(l.self.wsum, 3 * d * 4, false);
+            ALLOC(l.cross.bln, d * 4, false);
+            ALLOC(l.cross.wsum, d * 4, false);
+            ALLOC(l.b1ln, f * 4, false);
+            ALLOC(l.w1sum, f * 4, false);
+            char* t = (char*)tmp;
+            const size_t dd = (size_t)d * d * c->es;
+            RUN(uw_fold_layernorm(c->dt, l.self.src_wq, l.self.src_bq, l.self.ln_g, l.self.ln_b, 0.125f, t, l.self.bln, l.self.wsum, (int)d, (int)d, 0));
+            RUN(uw_fold_layernorm(c->dt, l.self.src_wk, nullptr, l.self.ln_g, l.self.ln_b, 1.f, t + dd, l.self.bln + d, l.self.wsum + d, (int)d, (int)d, 0));
+            RUN(uw_fold_layernorm(c->dt, l.self.src_wv, l.self.src_bv, l.self.ln_g, l.self.ln_b, 1.f, t + 2 * dd, l.self.bln + 2 * d, l.self.wsum + 2 * d, (int)d, (int)d, 0));
+            RUN(uw_pack_frag(c->dt, t, d, l.self.wqkv_p, (int)(3 * d), (int)d, 0));
+            RUN(uw_fold_layernorm(c->dt, l.cross.src_wq, l.cross.src_bq, l.cross.ln_g, l.cross.ln_b, 0.125f, t, l.cross.bln, l.cross.wsum, (int)d, (int)d, 0));
+            RUN(uw_pack_frag(c->dt, t, d, l.cross.wq_p, (int)d, (int)d, 0));
+            RUN(uw_fold_layernorm(c->dt, l.src_w1, l.src_b1, l.ln2_g, l.ln2_b, 1.f, t, l.b1ln, l.w1sum, (int)f, (int)d, 0));
+            RUN(uw_pack_frag(c->dt, t, d, l.w1_p, (int)f, (int)d, 0));
+            RUN(uw_pack_frag(c->dt, l.self.wo, d, l.self.wo_p, (int)d, (int)d, 0));
+            RUN(uw_pack_frag(c->dt, l.cross.wo, d, l.cross.wo_p, (int)d, (int)d, 0));
+            RUN(uw_pack_frag(c->dt, l.w2, f, l.w2_p, (int)d, (int)f, 0));
+        }
+        UW_HIP_CHECK(hipDeviceSynchronize());
+        UW_HIP_CHECK(hipFree(tmp));
     }
     const float *dlg = cur.next(), *dlb = cur.next();
     ALLOC(c->dec_ln_g, d * 4, false);
@@ -362,7 +389,20 @@ int gemm_step(uw_ctx* c, const void* A, const void* Wp, void* C, long ldc, bool 
     p.bias_mode = bias ? 1 : 0;
     p.act = act;
     p.ab_packed = 1; p.c_packed = c_packed ? 1 : 0;
+    p.c_xlayout = residual ? 1 : 0;   // the step's residual stream lives in the x layout
     return uw_gemm_skinny(c->dt, out_f32 ? 1 : 0, p, s);
+}
+
+// decode-step product with the preceding LayerNorm folded in: A is the residual stream x (x layout)
+int gemm_step_ln(uw_ctx* c, const float* x, const void* Wp, const float* bias_ln, const float* wsum, void* C, long ldc, int M, int N,
+                 int K, int act, bool c_packed, hipStream_t s)
+{
+    GemmParams p;
+    p.A = x; p.B = Wp; p.C = C; p.bias = bias_ln; p.wsum = wsum;
+    p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    p.bias_mode = 1; p.act = act;
+    p.ab_packed = 1; p.c_packed = c_packed ? 1 : 0; p.ln_fused = 1;
+    return uw_gemm_skinny(c->dt, 0, p, s);
 }
 
 int encoder_forward(uw_ctx* c, const float* mel, int B, hipStream_t s)
@@ -512,6 +552,8 @@ int decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, con
     return UW_OK;
 }
 
+// writes the step's residual stream in the x layout (x_elem_offset): row b of the call = window b0 + b
+template <typename T>
 __global__ void embed_step_kernel(float* __restrict__ x, const float* __restrict__ tok_emb, const float* __restrict__ pos_emb,
                                   const int32_t* __restrict__ tokens, int ld_tok, const int32_t* __restrict__ pos, int d, int vocab,
                                   int n_ctx)
@@ -521,8 +563,7 @@ __global__ void embed_step_kernel(float* __restrict__ x, const float* __restrict
     const int id = min(max(tokens[(long)b * ld_tok + p], 0), vocab - 1);
     const f32x4* e = (const f32x4*)(tok_emb + (long)id * d);
     const f32x4* pe = (const f32x4*)(pos_emb + (long)p * d);
-    f32x4* o = (f32x4*)(x + (long)b * d);
-    for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) o[i] = e[i] + pe[i];
+    for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) *(f32x4*)(x + x_elem_offset<T>(b, i * 4, d)) = e[i] + pe[i];
 }
 
 // one KV-cached decoder step for the token at st_pos[b] of windows [b0, b0 + B) -> their rows of c->logits.
@@ -539,21 +580,22 @@ int decoder_step(uw_ctx* c, int b0, int B, hipStream_t s)
     float* logits = c->logits + (long)b0 * c->logits_ld;
     const int32_t* pos = c->st_pos + b0;
     const int32_t* active = c->st_active + b0;
-    hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, s, x, c->tok_emb32, c->dec_pos, c->st_tokens + (long)b0 * Tm, Tm, pos, d, c->V, Tm);
+    if (c->dt == UW_F32)
+        hipLaunchKernelGGL(embed_step_kernel<float>, dim3(B), dim3(256), 0, s, x, c->tok_emb32, c->dec_pos, c->st_tokens + (long)b0 * Tm, Tm, pos, d, c->V, Tm);
+    else
+        hipLaunchKernelGGL(embed_step_kernel<bf16_t>, dim3(B), dim3(256), 0, s, x, c->tok_emb32, c->dec_pos, c->st_tokens + (long)b0 * Tm, Tm, pos, d, c->V, Tm);
     UW_LAUNCH_CHECK();
     for (size_t li = 0; li < c->dec.size(); ++li) {
         auto& l = c->dec[li];
         char* skv = (char*)c->self_kv + li * self_kv_layer_bytes(c) + (size_t)b0 * Tm * 2 * d * es;
         char* ckv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c) + (size_t)b0 * S * 2 * d * es;
-        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.self.ln_g, l.self.ln_b, B, d, s, 1));
-        RUN(gemm_step(c, ln, l.self.wqkv_p, qkv, 3 * d, false, B, 3 * d, d, l.self.bqkv, 0, nullptr, 0, false, s));
+        RUN(gemm_step_ln(c, x, l.self.wqkv_p, l.self.bln, l.self.wsum, qkv, 3 * d, B, 3 * d, d, 0, false, s));
         SelfDecodeParams sp;
         sp.qkv = qkv; sp.kcache = skv; sp.vcache = skv + (size_t)Tm * d * es; sp.out = att;
         sp.pos = pos; sp.active = active; sp.ld_cache = 64; sp.cache_sB = (long)Tm * 2 * d; sp.cache_sH = (long)Tm * 64; sp.out_packed = 1; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
         RUN(uw_self_attn_decode(c->dt, sp, s));
         RUN(gemm_step(c, att, l.self.wo_p, x, d, true, B, d, d, l.self.bo, 0, x, d, false, s));
-        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.cross.ln_g, l.cross.ln_b, B, d, s, 1));
-        RUN(gemm_step(c, ln, l.cross.wq_p, qkv, d, false, B, d, d, l.cross.bq, 0, nullptr, 0, false, s));
+        RUN(gemm_step_ln(c, x, l.cross.wq_p, l.cross.bln, l.cross.wsum, qkv, d, B, d, d, 0, false, s));
         CrossDecodeParams cp;
         cp.q = qkv; cp.K = ckv; cp.V = ckv + (size_t)S * d * es; cp.out = att;
         cp.rows_sB = (long)c->n_sel * Tm * S; cp.rows_sSel = (long)Tm * S;
@@ -570,11 +612,10 @@ int decoder_step(uw_ctx* c, int b0, int B, hipStream_t s)
         if (timed) { UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used + 1], s)); c->prof_used += 2; }
         if (c->prof_on) { ++c->prof_launches; c->prof_windows += B; }
         RUN(gemm_step(c, att, l.cross.wo_p, x, d, true, B, d, d, l.cross.bo, 0, x, d, false, s));
-        RUN(uw_layernorm(c->dt, x, ln, nullptr, l.ln2_g, l.ln2_b, B, d, s, 1));
-        RUN(gemm_step(c, ln, l.w1_p, mlp, 4 * d, false, B, 4 * d, d, l.b1, 1, nullptr, 0, true, s));
+        RUN(gemm_step_ln(c, x, l.w1_p, l.b1ln, l.w1sum, mlp, 4 * d, B, 4 * d, d, 1, true, s));
         RUN(gemm_step(c, mlp, l.w2_p, x, d, true, B, d, 4 * d, l.b2, 0, x, d, false, s));
     }
-    RUN(uw_layernorm(c->dt, x, ln, nullptr, c->dec_ln_g, c->dec_ln_b, B, d, s));
+    RUN(uw_layernorm(c->dt, x, ln, nullptr, c->dec_ln_g, c->dec_ln_b, B, d, s, 0, 1));
     RUN(gemm(c, ln, d, c->tok_emb, d, logits, c->logits_ld, true, B, c->V, d, nullptr, 0, nullptr, 0, s));
     return UW_OK;
 }

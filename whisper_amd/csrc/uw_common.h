@@ -118,6 +118,20 @@ template <typename T> __host__ __device__ __forceinline__ long frag_elem_offset(
     return (((((r >> 4) * steps + (chunk >> 2)) << 6) + ((chunk & 3) << 4) + (r & 15)) * E) + (k % E);
 }
 
+// Layout of the f32 residual stream inside the decode step.  The step's LayerNorm-fused GEMMs read x itself as
+// their MFMA operand (normalisation is applied to the product, see gemm_step_ln_kernel), so x is kept the way
+// an operand block is fetched: for f32 compute the plain fragment-major layout; for bf16 compute a lane needs 8
+// consecutive columns (32 bytes of f32) per 32-column step, stored as two 1 KiB halves of 4 columns per lane.
+template <typename T> __host__ __device__ __forceinline__ long x_elem_offset(long m, int k, int K)
+{
+    if constexpr (sizeof(T) == 4) {
+        return frag_elem_offset<float>(m, k, K);
+    } else {
+        const int steps = K >> 5;
+        return ((((((m >> 4) * steps + (k >> 5)) << 1) + ((k >> 2) & 1)) << 6) + (((k >> 3) & 3) << 4) + (m & 15)) * 4 + (k & 3);
+    }
+}
+
 // erf by the rational form of Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 before rounding): one reciprocal,
 // one exponential and five FMAs instead of the library routine's branches; the GELU of a GEMM epilogue is
 // evaluated once per output element, which made the library erf as expensive as the tile's MFMAs.

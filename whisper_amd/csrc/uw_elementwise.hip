@@ -10,7 +10,7 @@ namespace {
 template <typename T, int NI>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, T* __restrict__ y,
                                                         float* __restrict__ y32, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, long rows, int d, int packed)
+                                                        const float* __restrict__ beta, long rows, int d, int packed, int x_layout)
 {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < NI; ++i) {
         const int c = lane + i * 64;
         const bool in = c < nv;
-        v[i] = in ? xr[c] : zero;
+        v[i] = in ? (x_layout ? *(const f32x4*)(x + x_elem_offset<T>(row, c * 4, d)) : xr[c]) : zero;
         g[i] = in ? ((const f32x4*)gamma)[c] : zero;
         bb[i] = in ? ((const f32x4*)beta)[c] : zero;
     }
@@ -65,6 +65,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                 }
             }
         }
+    }
+}
+
+// one wave per weight row: LayerNorm scale folded into the row, shift folded into the bias, row sum of the
+// rounded row kept for the mean correction
+template <typename T>
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ w, const float* __restrict__ bias_in,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float scale, T* __restrict__ dst, float* __restrict__ bias_out,
+                                                             float* __restrict__ wsum, int N, int K)
+{
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float sb = 0.f, sw = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = w[(long)n * K + k];
+        const T r = from_f32<T>(wv * scale * gamma[k]);
+        dst[(long)n * K + k] = r;
+        sw += to_f32<T>(r);
+        sb += wv * beta[k];
+    }
+    sb = wave_sum(sb);
+    sw = wave_sum(sw);
+    if (lane == 0) {
+        bias_out[n] = scale * ((bias_in ? bias_in[n] : 0.f) + sb);
+        wsum[n] = sw;
     }
 }
 
@@ -182,7 +208,7 @@ inline int stream_grid(long n, int block) { return (int)(n / block + 1 < 4096 ? 
 }  // namespace
 
 int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* gamma, const float* beta, long rows,
-                 int d, hipStream_t s, int packed)
+                 int d, hipStream_t s, int packed, int x_layout)
 {
     UW_REQUIRE(d % 4 == 0 && d <= 2048 && rows > 0, "layernorm: d=%d rows=%ld unsupported", d, rows);
     UW_REQUIRE(!packed || d % (dtype == UW_F32 ? 16 : 32) == 0, "layernorm: packed output needs d=%d to be a multiple of 64 bytes", d);
@@ -190,8 +216,8 @@ int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* ga
     const int ni = (d / 4 + 63) / 64;
 #define UW_LN_LAUNCH(NI)                                                                                                         \
     do {                                                                                                                         \
-        if (dtype == UW_F32) hipLaunchKernelGGL((layernorm_kernel<float, NI>), grid, dim3(256), 0, s, x, (float*)y, y32, gamma, beta, rows, d, packed); \
-        else hipLaunchKernelGGL((layernorm_kernel<bf16_t, NI>), grid, dim3(256), 0, s, x, (bf16_t*)y, y32, gamma, beta, rows, d, packed);              \
+        if (dtype == UW_F32) hipLaunchKernelGGL((layernorm_kernel<float, NI>), grid, dim3(256), 0, s, x, (float*)y, y32, gamma, beta, rows, d, packed, x_layout); \
+        else hipLaunchKernelGGL((layernorm_kernel<bf16_t, NI>), grid, dim3(256), 0, s, x, (bf16_t*)y, y32, gamma, beta, rows, d, packed, x_layout);    \
     } while (0)
     if (ni <= 1) UW_LN_LAUNCH(1);
     else if (ni <= 2) UW_LN_LAUNCH(2);
@@ -200,6 +226,17 @@ int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* ga
     else if (ni <= 6) UW_LN_LAUNCH(6);
     else UW_LN_LAUNCH(8);
 #undef UW_LN_LAUNCH
+    UW_LAUNCH_CHECK();
+    return UW_OK;
+}
+
+int uw_fold_layernorm(int dtype, const float* w, const float* bias_in, const float* gamma, const float* beta, float scale,
+                      void* dst, float* bias_out, float* wsum, int N, int K, hipStream_t s)
+{
+    UW_REQUIRE(w && gamma && beta && dst && bias_out && wsum && N > 0 && K > 0, "fold_layernorm: missing argument");
+    const dim3 grid((N + 3) / 4);
+    if (dtype == UW_F32) hipLaunchKernelGGL(fold_layernorm_kernel<float>, grid, dim3(256), 0, s, w, bias_in, gamma, beta, scale, (float*)dst, bias_out, wsum, N, K);
+    else hipLaunchKernelGGL(fold_layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, w, bias_in, gamma, beta, scale, (bf16_t*)dst, bias_out, wsum, N, K);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
             e_bias = f32x4{b, b, b, b};
         }
         if (R) {
-            if (vec_ok) e_res = *(const f32x4*)(R + (long)e_m * p.ldr + e_n);
+            if (vec_ok) e_res = *(const f32x4*)(R + (p.c_xlayout ? x_elem_offset<T>(e_m, e_n, p.N) : (long)e_m * p.ldr + e_n));
             else
 #pragma unroll
                 for (int r = 0; r < 4; ++r) e_res[r] = (e_n + r < p.N) ? R[(long)e_m * p.ldr + e_n + r] : 0.f;
@@ -647,6 +647,184 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
     }
     v += e_res;
     if (vec_ok) {
+        const long at = p.c_packed ? frag_elem_offset<TC>(e_m, e_n, p.N) : (p.c_xlayout ? x_elem_offset<T>(e_m, e_n, p.N) : c_off(p, e_m, e_n));
+        if constexpr (sizeof(TC) == 4) {
+            *(f32x4*)((float*)C + at) = v;
+        } else {
+            union { bf16_t h[4]; uint2 u; } pk;
+            pk.h[0] = (bf16_t)v[0]; pk.h[1] = (bf16_t)v[1]; pk.h[2] = (bf16_t)v[2]; pk.h[3] = (bf16_t)v[3];
+            *(uint2*)((bf16_t*)C + at) = pk.u;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (e_n + r >= p.N) break;
+            C[c_off(p, e_m, e_n) + r] = from_f32<TC>(v[r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny form with the LayerNorm in front of the linear layer fused in.  A is the f32 residual stream x in the
+// step's x layout, W holds gamma-scaled weights (fragment-major), and
+//     LN(x) W^T + b  =  rstd * (x W'^T - mean * wsum) + b',      W' = W diag(gamma), b' = b + W beta, wsum = W' 1
+// so the product runs on x as it is and the row statistics -- which the workgroup gets for free from the very
+// operand blocks it loads, every wave summing its K slice -- enter only in the epilogue.  For bf16 compute x is
+// split into a high and a low bf16 part (two MFMAs per block, the matrix cores idle in this kernel anyway), which
+// keeps ~16 mantissa bits of x: more than rounding a normalised row to bf16 keeps.
+template <typename T, typename TC, int MT, int NT>
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_step_ln_kernel(GemmParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = 16 / (int)sizeof(T);
+    constexpr int KS = 4 * E;
+    constexpr int AH = sizeof(T) == 2 ? 2 : 1;          // 16-byte pieces of x per operand chunk
+    constexpr int A_STEP = 1024 * AH;                    // bytes of x per (row block, K step)
+    f32x4* part = (f32x4*)smem;                          // [SK_WAVES][MT * NT][64]
+    float* stat = (float*)(part + SK_WAVES * MT * NT * 64);   // [SK_WAVES][MT][16][2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * (NT * 16), m0 = blockIdx.y * (MT * 16);
+    const int steps_total = p.K / KS;
+    const int s_begin = (steps_total * wave) / SK_WAVES, s_end = (steps_total * (wave + 1)) / SK_WAVES;
+    const int n_blocks = (p.N + 15) >> 4, m_blocks = (p.M + 15) >> 4;
+    const __amdgpu_buffer_rsrc_t rsW =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)((long)n_blocks * 16 * p.K * (int)sizeof(T)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((long)m_blocks * 16 * p.K * 4), 0x00020000);
+    int woff[NT], aoff[MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) woff[nt] = min((n0 >> 4) + nt, n_blocks - 1) * steps_total * 1024 + lane * 16;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) aoff[mt] = min((m0 >> 4) + mt, m_blocks - 1) * steps_total * A_STEP + lane * 16;
+
+    // epilogue operands of the tile this wave finishes, requested up front
+    static_assert(MT * NT <= SK_WAVES, "one output tile per wave");
+    TC* __restrict__ C = (TC*)p.C;
+    const int e_mt = wave / NT, e_nt = wave % NT;
+    const int e_m = m0 + e_mt * 16 + fr, e_n = n0 + e_nt * 16 + fg * 4;
+    const bool e_live = wave < MT * NT && e_m < p.M && e_n < p.N;
+    f32x4 e_bias = {0.f, 0.f, 0.f, 0.f}, e_wsum = {0.f, 0.f, 0.f, 0.f};
+    if (e_live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            e_bias[r] = (p.bias && e_n + r < p.N) ? p.bias[e_n + r] : 0.f;
+            e_wsum[r] = (e_n + r < p.N) ? p.wsum[e_n + r] : 0.f;
+        }
+    }
+
+    f32x4 acc[MT][NT];
+    float sx[MT], sxx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        sx[mt] = 0.f; sxx[mt] = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto ld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) -> uint4 {
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+    uint4 wv[2][SK_ROUND][NT], xv[2][SK_ROUND][MT][AH];
+    auto load_round = [&](int buf, int s) {
+#pragma unroll
+        for (int r = 0; r < SK_ROUND; ++r) {
+            const int st = min(s + r, s_end - 1);   // steps past the end re-read the last one (unused)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wv[buf][r][nt] = ld(rsW, woff[nt], st * 1024);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int h = 0; h < AH; ++h) xv[buf][r][mt][h] = ld(rsA, aoff[mt] + h * 1024, st * A_STEP);
+        }
+    };
+    auto mma_round = [&](int buf, int s) {
+#pragma unroll
+        for (int r = 0; r < SK_ROUND; ++r) {
+            if (s + r < s_end) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if constexpr (sizeof(T) == 4) {
+                        const uint4 a = xv[buf][r][mt][0];
+                        const float f0 = __uint_as_float(a.x), f1 = __uint_as_float(a.y), f2 = __uint_as_float(a.z), f3 = __uint_as_float(a.w);
+                        sx[mt] += (f0 + f1) + (f2 + f3);
+                        sxx[mt] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) mma16<T>(wv[buf][r][nt], a, acc[mt][nt]);
+                    } else {
+                        const uint4 a0 = xv[buf][r][mt][0], a1 = xv[buf][r][mt][AH - 1];
+                        const float f[8] = {__uint_as_float(a0.x), __uint_as_float(a0.y), __uint_as_float(a0.z), __uint_as_float(a0.w),
+                                            __uint_as_float(a1.x), __uint_as_float(a1.y), __uint_as_float(a1.z), __uint_as_float(a1.w)};
+                        union { bf16_t h[8]; uint4 u; } hi, lo;
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            hi.h[e] = (bf16_t)f[e];
+                            lo.h[e] = (bf16_t)(f[e] - (float)hi.h[e]);
+                            s1 += f[e];
+                            s2 = fmaf(f[e], f[e], s2);
+                        }
+                        sx[mt] += s1;
+                        sxx[mt] += s2;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            mma16<T>(wv[buf][r][nt], hi.u, acc[mt][nt]);
+                            mma16<T>(wv[buf][r][nt], lo.u, acc[mt][nt]);
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (s_begin < s_end) {
+        load_round(0, s_begin);
+        for (int s = s_begin; s < s_end; s += 2 * SK_ROUND) {
+            if (s + SK_ROUND < s_end) load_round(1, s + SK_ROUND);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_round(0, s);
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + SK_ROUND < s_end) {
+                if (s + 2 * SK_ROUND < s_end) load_round(0, s + 2 * SK_ROUND);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_round(1, s + SK_ROUND);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) part[(wave * MT * NT + mt * NT + nt) * 64 + lane] = acc[mt][nt];
+        // row sums over the four 16-lane groups (the four chunks of a step), one (sum, sum of squares) per row
+        float a = sx[mt], b = sxx[mt];
+        a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+        a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+        if (fg == 0) {
+            stat[((wave * MT + mt) * 16 + fr) * 2 + 0] = a;
+            stat[((wave * MT + mt) * 16 + fr) * 2 + 1] = b;
+        }
+    }
+    __syncthreads();
+    if (!e_live) return;
+    f32x4 t = part[wave * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < SK_WAVES; ++w) t += part[(w * MT * NT + wave) * 64 + lane];
+    float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) {
+        S1 += stat[((w * MT + e_mt) * 16 + fr) * 2 + 0];
+        S2 += stat[((w * MT + e_mt) * 16 + fr) * 2 + 1];
+    }
+    const float inv_k = 1.0f / (float)p.K;
+    const float mean = S1 * inv_k;
+    const float var = fmaxf(S2 * inv_k - mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r] = rstd * (t[r] - mean * e_wsum[r]) + e_bias[r];
+        if (p.act == 1) v[r] = gelu_erf(v[r]);
+    }
+    if (e_n + 3 < p.N && (p.c_packed || (p.ldc & 3) == 0)) {
         const long at = p.c_packed ? frag_elem_offset<TC>(e_m, e_n, p.N) : c_off(p, e_m, e_n);
         if constexpr (sizeof(TC) == 4) {
             *(f32x4*)((float*)C + at) = v;
@@ -689,6 +867,29 @@ template <typename T, typename TC, int MT, int NT> int launch_skinny_mt(const Ge
     return UW_OK;
 }
 
+template <typename T, typename TC, int MT, int NT> int launch_step_ln_mt(const GemmParams& p, hipStream_t s)
+{
+    const size_t lds = (size_t)SK_WAVES * MT * NT * 64 * sizeof(f32x4) + (size_t)SK_WAVES * MT * 16 * 2 * sizeof(float);
+    const dim3 grid((p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
+    hipLaunchKernelGGL((gemm_step_ln_kernel<T, TC, MT, NT>), grid, dim3(64 * SK_WAVES), lds, s, p);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
+}
+
+template <typename T, typename TC> int launch_step_ln(const GemmParams& p, hipStream_t s)
+{
+    constexpr int KS = 64 / (int)sizeof(T);
+    UW_REQUIRE(p.M > 0 && p.M <= 128 && p.N > 0 && p.K > 0 && p.batch == 1 && p.ab_packed && p.wsum && !p.residual && !p.c_group,
+               "LayerNorm-fused gemm: unsupported arguments (M=%d)", p.M);
+    UW_REQUIRE(p.K % KS == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, "LayerNorm-fused gemm: K=%d or alignment", p.K);
+    UW_REQUIRE(!p.c_packed || (sizeof(TC) == sizeof(T) && p.N % KS == 0), "LayerNorm-fused gemm: packed output needs N=%d a multiple of %d", p.N, KS);
+    // measured on MI355X at M = 128: the f32 operand and its bf16 split are amortised over four column tiles when
+    // N is wide; a narrow N keeps 16-row workgroups so that the grid still covers most CUs
+    if (p.M <= 16) return p.N >= 2048 ? launch_step_ln_mt<T, TC, 1, 2>(p, s) : launch_step_ln_mt<T, TC, 1, 1>(p, s);
+    if (p.N >= 2048) return launch_step_ln_mt<T, TC, 2, 4>(p, s);
+    return launch_step_ln_mt<T, TC, 1, 2>(p, s);
+}
+
 template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStream_t s)
 {
     constexpr int KS = 64 / (int)sizeof(T);
@@ -700,6 +901,8 @@ template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStr
     const long w_rows = p.ab_packed ? (long)((p.N + 15) & ~15) * p.K : (long)p.N * p.ldb;
     const long a_rows = p.ab_packed ? (long)((p.M + 15) & ~15) * p.K : (long)p.M * p.lda;
     UW_REQUIRE(w_rows * (long)sizeof(T) < (1l << 31) && a_rows * (long)sizeof(T) < (1l << 31), "skinny gemm: operands must be under 2 GiB");
+    UW_REQUIRE(!p.c_xlayout || (sizeof(TC) == 4 && p.N % KS == 0 && !p.c_group && !p.c_packed && (!p.residual || p.ldr == p.ldc)),
+               "skinny gemm: x-layout output needs f32 C, N=%d a multiple of %d and a residual of the same shape", p.N, KS);
     UW_REQUIRE(!p.c_packed || (sizeof(TC) == sizeof(T) && p.N % KS == 0 && !p.c_group),
                "skinny gemm: packed output needs the compute dtype and N=%d a multiple of %d", p.N, KS);
     // 16 x 16 output tiles per workgroup: few rows per workgroup keep its activation traffic small; wide N takes
@@ -713,6 +916,11 @@ template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStr
 
 int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
 {
+    if (p.ln_fused) {
+        if (dtype == UW_F32) return launch_step_ln<float, float>(p, s);
+        if (out_f32) return launch_step_ln<bf16_t, float>(p, s);
+        return launch_step_ln<bf16_t, bf16_t>(p, s);
+    }
     if (dtype == UW_F32) return launch_skinny<float, float>(p, s);
     if (out_f32) return launch_skinny<bf16_t, float>(p, s);
     return launch_skinny<bf16_t, bf16_t>(p, s);

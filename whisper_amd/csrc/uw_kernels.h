@@ -21,6 +21,11 @@ struct GemmParams {
     int bias_mode = 0;  // 0 none, 1 bias[n], 2 bias[m]
     int act = 0;        // 0 none, 1 GELU(erf)
     int ab_packed = 0, c_packed = 0;  // fragment-major operands / output (skinny form only)
+    int c_xlayout = 0;                // skinny form: f32 C and residual are in the step's x layout (x_elem_offset)
+    // skinny form, LayerNorm fused: A is the f32 residual stream in the x layout, B holds gamma-scaled weights,
+    // bias holds bias + W.beta, wsum[n] = sum_k B[n][k]; C = rstd * (A.B^T - mean * wsum) + bias
+    int ln_fused = 0;
+    const float* wsum = nullptr;
     long c_group = 0;   // 0: C[m][n] at m*ldc + n.  Else columns are stored in groups of 64 (one attention head):
                         // C[m][n] at (n / 64) * c_group + m * ldc + (n % 64), ldc = 64 for a head-contiguous cache
 };
@@ -37,7 +42,11 @@ int uw_pack_frag(int dtype, const void* src, long ld, void* dst, int R, int K, h
 // y[r][:] = LayerNorm(x[r][:]) * gamma + beta, eps 1e-5.  y in dtype; y32 (optional) also gets f32.
 // packed: y is written fragment-major (frag_elem_offset), the A operand of the decode-step GEMMs
 int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* gamma, const float* beta, long rows,
-                 int d, hipStream_t s, int packed = 0);
+                 int d, hipStream_t s, int packed = 0, int x_layout = 0);
+// LayerNorm folded into the following linear layer (rows of w): dst[n][k] = T(w[n][k] * scale * gamma[k]),
+// bias_out[n] = scale * (bias_in[n] + sum_k w[n][k] * beta[k]), wsum[n] = sum_k float(dst[n][k])
+int uw_fold_layernorm(int dtype, const float* w, const float* bias_in, const float* gamma, const float* beta, float scale,
+                      void* dst, float* bias_out, float* wsum, int N, int K, hipStream_t s);
 // dst (dtype) = src (f32) * scale, n elements
 int uw_convert(int dtype, const float* src, void* dst, long n, float scale, hipStream_t s);
 // conv weight [co][ci][3] f32 -> [co][kpad] dtype with k index = tap * ci_count + ci, zero padded to kpad
