@@ -175,6 +175,16 @@ def main():
     bytes_per_launch = windows_per_launch * 2 * 1500 * dims.d_model * es
     avg_ms = prof["timed_ms"] / max(1, prof["timed"])
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM bytes per launch of the same kernel from the PMC counters (separate rocprofv3 --pmc passes, summary
+    # committed under profiles/); only quoted when it was measured on this very configuration
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_cross_decode.json")) as fh:
+            pmc = json.load(fh)
+        if (pmc["model"], pmc["batch"], pmc["dtype"]) == (args.model, B, args.dtype) and abs(windows_per_launch - B) < 1e-9:
+            traffic = pmc["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     line = {
         "metric": "audio-sec/sec (RTFx) whole node, whisper-small greedy + word timestamps",
         "value": value, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -186,7 +196,7 @@ def main():
                    "global_batch": B * world, "prompt_len": P, "generated_per_window": float(n_new.mean()),
                    "text_tokens_per_window": float(n_text.mean()), "parallelism": f"dp{world} (independent windows)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                     "traffic": None, "kernel": "cross_decode_kernel", "bytes_per_launch": bytes_per_launch, "windows_per_launch": windows_per_launch,
+                     "traffic": traffic, "kernel": "cross_decode_kernel", "bytes_per_launch": bytes_per_launch, "windows_per_launch": windows_per_launch,
                      "avg_launch_ms": avg_ms, "launches_timed": prof["timed"], "launches": prof["launches"]},
     }
     if rank == 0:

@@ -10,7 +10,7 @@ flt = sys.argv[2] if len(sys.argv) > 2 else ""
 f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for r in csv.DictReader(open(f)):
-    name = r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:70]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
     if flt and flt not in name:
         continue
     key = f"{name} grid={r['Grid_Size']}"

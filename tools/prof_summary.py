@@ -11,7 +11,7 @@ f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
 g = collections.defaultdict(lambda: [0, 0.0])
 for r in csv.DictReader(open(f)):
     n = r["Kernel_Name"]
-    short = n.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")
+    short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     for a, b in (("_ZN12_GLOBAL__N_1", ""),):
         short = short.replace(a, b)
     key = short[:60]
