@@ -72,6 +72,14 @@ int uw_cross_kv(uw_ctx* ctx, const float* enc_states, int B, void* stream);
 int uw_decoder_forward(uw_ctx* ctx, const int32_t* ids, int ld_ids, int B, int T, float* logits_all,
                        float* logits_last, float* cross_probs, void* stream);
 
+/* Decoder seam, KV-cached form: one decoder_sess.run of the greedy loop (core.py:941-949) for the newest token
+ * only.  The reference's decoder declares past_key_values.* inputs but always feeds them empty (core.py:185-192,
+ * 943-946) and so re-runs the whole prefix; here the self-attention K/V of earlier positions stay in the context
+ * (written by uw_decoder_forward or by earlier steps), so window b's positions 0..pos[b]-1 must have been
+ * processed first.  ids, pos: i32 [B] device arrays; logits: f32 [B][vocab] for the token at pos[b].  A pos
+ * outside 0..n_text_ctx-1 skips that window.  Invalidates the state of a uw_decode_greedy in progress. */
+int uw_decode_step(uw_ctx* ctx, const int32_t* ids, const int32_t* pos, int B, float* logits, void* stream);
+
 /* Greedy loop seam: core.py:938-968 plus the text filter of core.py:991, KV-cached.  prompt_ids: i32
  * [B][ld_prompt], prompt_len: i32 [B] HOST array, max_tokens: total sequence budget (prompt included).
  * Outputs (device): new_tokens i32 [B][n_text_ctx], n_new i32 [B], text_ids i32 [B][n_text_ctx], n_text i32 [B].

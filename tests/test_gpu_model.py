@@ -77,6 +77,20 @@ def test_decoder_forward_matches_oracle(micro, mode, tol_logits, tol_probs):
         assert np.allclose(got.sum(-1), 1.0, atol=1e-4)
 
 
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-4), ("bf16", 3e-2)])
+def test_decode_step_continues_a_prefix(micro, mode, tol):
+    """KV-cached single steps after a cache-less pass over the prefix reproduce the cache-less logits."""
+    eng, om, enc = micro[mode], micro["om"], micro["enc"]
+    eng.cross_kv(2, torch.from_numpy(enc).to(DEV))
+    ids = [[824, 825, 826, 924, 5, 17, 900, 3, 321], [824, 826, 924, 9, 9, 9, 1000, 1, 2]]
+    eng.decoder_forward(torch.tensor([r[:6] for r in ids], dtype=torch.int32), logits_last=True)
+    for t in range(6, 9):
+        got = eng.decode_step(torch.tensor([r[t] for r in ids]), torch.tensor([t, t])).cpu().numpy()
+        for b in range(2):
+            ref = om.decode_full(ids[b][: t + 1], enc[b: b + 1])[0, -1]
+            assert np.abs(got[b] - ref).max() < tol, (t, b, np.abs(got[b] - ref).max())
+
+
 def _reference_window(om, enc, prompt, max_tokens, sp):
     new = O.greedy_reference_schedule(om, enc, prompt, max_tokens, sp["eot"])
     text = O.filter_text_tokens(new, sp["sot"], sp["ts_begin"], sp["ts_end"])

@@ -854,6 +854,37 @@ int uw_decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, 
     return UW_OK;
 }
 
+namespace {
+__global__ void step_state_kernel(int32_t* __restrict__ tokens, int ld_tok, int32_t* __restrict__ st_pos, int32_t* __restrict__ st_active,
+                                  int32_t* __restrict__ st_n_text, const int32_t* __restrict__ ids, const int32_t* __restrict__ pos,
+                                  int B, int n_ctx)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int p = pos[b];
+    const bool ok = p >= 0 && p < n_ctx;
+    if (ok) tokens[(long)b * ld_tok + p] = ids[b];
+    st_pos[b] = ok ? p : 0;
+    st_active[b] = ok ? 1 : 0;      // a position outside the context leaves the window's logits untouched
+    st_n_text[b] = -1;              // no attention-row capture
+}
+}  // namespace
+
+int uw_decode_step(uw_ctx* c, const int32_t* ids, const int32_t* pos, int B, float* logits, void* stream)
+{
+    RUN(check_batch(c, B));
+    UW_REQUIRE(ids && pos && logits, "uw_decode_step: null argument");
+    UW_REQUIRE(B <= c->cross_batch, "uw_decode_step: call uw_cross_kv for these %d windows first", B);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(step_state_kernel, dim3((B + 63) / 64), dim3(64), 0, s, c->st_tokens, c->Tm, c->st_pos, c->st_active, c->st_n_text,
+                       ids, pos, B, c->Tm);
+    UW_LAUNCH_CHECK();
+    RUN(decoder_step(c, 0, B, s));
+    UW_HIP_CHECK(hipMemcpy2DAsync(logits, (size_t)c->V * 4, c->logits, (size_t)c->logits_ld * 4, (size_t)c->V * 4, B,
+                                  hipMemcpyDeviceToDevice, s));
+    return UW_OK;
+}
+
 int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const int32_t* prompt_len_host, int B, int max_tokens,
                      int eot, int sot, int ts_begin, int ts_end, int32_t* new_tokens, int32_t* n_new, int32_t* text_ids,
                      int32_t* n_text, void* stream)

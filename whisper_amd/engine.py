@@ -130,6 +130,16 @@ class Engine:
             out["cross_probs"] = cp
         return out
 
+    def decode_step(self, ids: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+        """KV-cached single step: token ids[b] at position pos[b] -> logits f32 [B, vocab].  Earlier positions must
+        already be in the self-attention cache (decoder_forward over the prefix, or previous steps)."""
+        ids = ids.to(self.device, torch.int32).contiguous()
+        pos = pos.to(self.device, torch.int32).contiguous()
+        B = ids.shape[0]
+        out = torch.empty((B, self.dims.vocab), dtype=torch.float32, device=self.device)
+        L.check(self.lib.uw_decode_step(self.ctx, L.ptr(ids), L.ptr(pos), B, L.ptr(out), self._s()))
+        return out
+
     def _pack_prompts(self, prompts: Sequence[Sequence[int]]):
         B = len(prompts)
         lens = np.array([len(p) for p in prompts], dtype=np.int32)

@@ -43,6 +43,7 @@ SIGNATURES = {
     "uw_encode": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "uw_cross_kv": (C.c_int, [_vp, _vp, C.c_int, _vp]),
     "uw_decoder_forward": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "uw_decode_step": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "uw_decode_greedy": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "uw_attn_rows_forced": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i32), _vp, C.c_int, C.POINTER(_i32), C.c_int, _vp]),
