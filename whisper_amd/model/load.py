@@ -3,8 +3,9 @@
 `load_onnx_models(encoder_path, decoder_path, onnx_providers, verbose, exclude_providers)` keeps the reference's
 signature and provider-selection rules (load.py:13-53) with one provider: "MI355XExecutionProvider".  Weights
 are resolved by `resolve_weights`: a directory of HF-layout *.safetensors files, or "synthetic:<shape>" for the
-deterministic generator.  Reading initialisers out of .onnx files is not implemented (parity unpinned: no
-.onnx file exists offline to test a reader against); passing .onnx paths raises with that explanation."""
+deterministic generator, or the reference's own file pair (`encoder_model.onnx` + `decoder_model[_merged].onnx`,
+urro_whisper/model/download.py:217-276) whose initialisers are read by `onnx_weights` (parity unpinned: no exported
+Whisper graph exists offline; that reader is tested on files written by the test-suite)."""
 from __future__ import annotations
 
 import logging
@@ -25,11 +26,16 @@ AVAILABLE_PROVIDERS = [PROVIDER]
 def resolve_weights(model: str, encoder_path: Optional[str] = None, decoder_path: Optional[str] = None
                     ) -> Tuple[str, Dict[str, torch.Tensor]]:
     """-> (shape name, fp32 state dict)."""
-    for p in (encoder_path, decoder_path):
-        if p and p.endswith(".onnx"):
-            raise NotImplementedError(
-                "reading weights from .onnx graphs is not implemented; point `model` (or onnx_encoder) at a directory "
-                "of HF-layout .safetensors files instead")
+    if encoder_path and decoder_path and encoder_path.endswith(".onnx") and decoder_path.endswith(".onnx"):
+        # the reference's rule: user paths are used only if BOTH files exist (download.py:229-237)
+        if not (os.path.isfile(encoder_path) and os.path.isfile(decoder_path)):
+            raise FileNotFoundError(f"onnx files not found: '{encoder_path}', '{decoder_path}' (downloading is not available)")
+        from ..weights import check_state_dict
+        from .onnx_weights import load_onnx_pair
+        sd = load_onnx_pair(encoder_path, decoder_path)
+        name = model if model and not model.endswith(".onnx") else os.path.basename(os.path.dirname(os.path.abspath(encoder_path)))
+        check_state_dict(dims_for(name), sd)
+        return name, sd
     src = encoder_path or model
     if isinstance(src, str) and src.startswith("synthetic:"):
         name = src.split(":", 1)[1]
