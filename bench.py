@@ -45,7 +45,7 @@ def synth_audio_gpu(B: int, seed: int, device) -> torch.Tensor:
     return (noise + chirp[None]).contiguous()
 
 
-def cpu_baseline(dims, sd, heads, prompt, n_gen: int, n_sample_steps: int = 4):
+def cpu_baseline(dims, sd, heads, prompt, n_gen: int, n_sample_steps: int = 48):
     """The oracle (CPU restatement of the reference's schedule) on ONE window of the same workload, bounded:
     log-mel + encoder once, `n_sample_steps` of the n_gen cache-less greedy passes and as many of the n_gen
     attention-replay passes (prefix lengths spread evenly over the real range), extrapolated linearly."""
