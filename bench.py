@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--gen", type=int, default=128, help="tokens generated per window")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N > 1 on one GPU)")
+    ap.add_argument("--device", type=int, default=None, help="GPU index for every rank (rehearsal only; default LOCAL_RANK)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,11 +115,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    if args.device is not None:
+        local = args.device
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from whisper_amd import engine as E
     from whisper_amd.config import alignment_heads, alignment_heads_key, dims_for
@@ -159,7 +166,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_end()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -200,7 +207,7 @@ def main():
                      "avg_launch_ms": avg_ms, "launches_timed": prof["timed"], "launches": prof["launches"]},
     }
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the host baseline is reported by the single-GPU run only
             line["cpu_baseline"] = cpu_baseline(dims, sd, heads, prompt, args.gen)
         print(json.dumps(line), flush=True)
     eng.close()

@@ -22,11 +22,13 @@ def gather_results(local: Dict[str, torch.Tensor], n_windows: int, rank: int, wo
     if world == 1:
         return local
     most = max(len(shard_windows(n_windows, r, world)) for r in range(world))
+    via_host = dist.get_backend() == "gloo"      # gloo gathers host tensors only (CPU tests, single-GPU rehearsals)
     out: Dict[str, torch.Tensor] = {}
     for key, t in local.items():
-        pad = torch.zeros((most,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dev = torch.device("cpu") if via_host else t.device
+        pad = torch.zeros((most,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
         pad[: t.shape[0]] = t
         parts = [torch.empty_like(pad) for _ in range(world)]
         dist.all_gather(parts, pad)
-        out[key] = torch.cat([parts[r][: len(shard_windows(n_windows, r, world))] for r in range(world)], dim=0)
+        out[key] = torch.cat([parts[r][: len(shard_windows(n_windows, r, world))] for r in range(world)], dim=0).to(t.device)
     return out
