@@ -1,4 +1,5 @@
 """Host-side logic that surrounds the GPU path (no GPU needed)."""
+import pytest
 import numpy as np
 
 from whisper_amd import align as A
@@ -43,3 +44,18 @@ def test_synthetic_weights_are_deterministic_and_complete():
 def test_n_mels_rule_follows_model_string():
     assert CFG.n_mels_for("large-v3") == 128 and CFG.n_mels_for("large-v3-turbo") == 128
     assert CFG.n_mels_for("large") == 80 and CFG.n_mels_for("turbo") == 80 and CFG.n_mels_for("small") == 80
+
+
+def test_system_icu_word_breaker():
+    """The ctypes binding over the system's libicuuc gives ICU word boundaries (align.py:110-116 uses PyICU for the
+    same iterator); offsets are UTF-16 units like PyICU's."""
+    from whisper_amd import align as A
+    if not A._system_icu():
+        pytest.skip("no system ICU library")
+    t = "Hello, world! it's 3.5 degrees 日本語のテキスト"
+    spans = A._icu_c_word_spans(t, "en")
+    assert [t[a:b] for a, b in spans] == ["Hello", ",", " ", "world", "!", " ", "it's", " ", "3.5", " ", "degrees", " ",
+                                          "日本語", "の", "テキスト"]
+    assert spans[0][0] == 0 and spans[-1][1] == len(t) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    u = "a 😀 b"                                # one astral character = two UTF-16 units
+    assert A._icu_c_word_spans(u, "en")[-1][1] == len(u) + 1

@@ -84,9 +84,71 @@ def _has_letter(s: str) -> bool:
     return any(unicodedata.category(ch).startswith("L") for ch in s)
 
 
+_ICU_C = None       # (library, symbol suffix) of the system ICU, False once a lookup failed
+
+
+def _system_icu():
+    """libicuuc of the system through ctypes (its C symbols carry the major version: ubrk_open_70)."""
+    global _ICU_C
+    if _ICU_C is None:
+        _ICU_C = False
+        try:
+            import ctypes
+            import ctypes.util
+            import re
+            path = ctypes.util.find_library("icuuc")
+            if path:
+                lib = ctypes.CDLL(path)
+                m = re.search(r"\.so\.(\d+)", path)
+                for suffix in ([f"_{m.group(1)}"] if m else []) + [""] + [f"_{v}" for v in range(85, 48, -1)]:
+                    if hasattr(lib, "ubrk_open" + suffix):
+                        fn = getattr(lib, "ubrk_open" + suffix)
+                        fn.restype = ctypes.c_void_p
+                        fn.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int)]
+                        for name in ("ubrk_first", "ubrk_next"):
+                            g = getattr(lib, name + suffix)
+                            g.restype = ctypes.c_int32
+                            g.argtypes = [ctypes.c_void_p]
+                        getattr(lib, "ubrk_close" + suffix).argtypes = [ctypes.c_void_p]
+                        _ICU_C = (lib, suffix)
+                        break
+        except OSError:
+            pass
+    return _ICU_C
+
+
+def _icu_c_word_spans(text: str, lang: str) -> Optional[List[Tuple[int, int]]]:
+    """Word-boundary spans from ubrk_open(UBRK_WORD, lang).  Offsets are UTF-16 code units, exactly what PyICU hands
+    the reference (align.py:116, 187-189), which slices the Python string with them."""
+    icu_c = _system_icu()
+    if not icu_c:
+        return None
+    import ctypes
+    lib, suffix = icu_c
+    units = text.encode("utf-16-le")
+    buf = ctypes.create_string_buffer(units, len(units) + 2)
+    status = ctypes.c_int(0)
+    bi = getattr(lib, "ubrk_open" + suffix)(1, lang.encode(), ctypes.cast(buf, ctypes.c_void_p), len(units) // 2, ctypes.byref(status))
+    if status.value > 0 or not bi:
+        return None
+    try:
+        nxt = getattr(lib, "ubrk_next" + suffix)
+        spans, start = [], getattr(lib, "ubrk_first" + suffix)(bi)
+        while True:
+            end = nxt(bi)
+            if end < 0:           # UBRK_DONE
+                break
+            spans.append((start, end))
+            start = end
+        return spans
+    finally:
+        getattr(lib, "ubrk_close" + suffix)(bi)
+
+
 def default_word_breaker(text: str, lang: str = "en") -> List[Tuple[int, int]]:
-    """(start, end) character spans covering `text`.  Uses ICU's word BreakIterator when PyICU is importable
-    (what the reference does, align.py:110-116); otherwise runs of word characters / single other characters."""
+    """(start, end) spans covering `text` from ICU's word BreakIterator, as the reference uses (align.py:110-116):
+    PyICU when importable, else the system's libicuuc through ctypes; without any ICU, runs of word characters /
+    single other characters."""
     try:
         import icu  # type: ignore
         bi = icu.BreakIterator.createWordInstance(icu.Locale(lang))
@@ -97,6 +159,9 @@ def default_word_breaker(text: str, lang: str = "en") -> List[Tuple[int, int]]:
             start = end
         return spans
     except ImportError:
+        spans = _icu_c_word_spans(text, lang)
+        if spans is not None:
+            return spans
         import re
         return [(m.start(), m.end()) for m in re.finditer(r"[\w'’]+|\s+|[^\w\s]", text, flags=re.UNICODE)]
 
