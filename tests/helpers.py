@@ -23,3 +23,40 @@ def synth_audio(seed, n=480000):
 
 MICRO_SPECIALS = dict(sot=824, eot=823, ts_begin=924, ts_end=1023)       # vocab 1024
 WHISPER_SPECIALS = dict(sot=50258, eot=50257, ts_begin=50364, ts_end=51864)
+
+
+class WordTokenizer:
+    """Whisper-tokenizer-shaped stand-in over the multilingual id layout (no tokenizer files exist offline).
+    Text ids: 11 ',', 12 ' -', 13 ' >', 14 '.', every other id t < 50257 is the word ' w<t>'.  Used identically by the
+    golden generator (which drives the reference's own core.py) and by the tests of this package's host logic."""
+    eot, sot, sot_prev, no_timestamps, timestamp_begin = 50257, 50258, 50361, 50363, 50364
+    transcribe, translate, task = 50359, 50358, 50359
+    language = "en"
+    _PUNCT = {11: ",", 12: " -", 13: " >", 14: "."}
+
+    def decode(self, ids):
+        out = []
+        for t in ids:
+            t = int(t)
+            if t in self._PUNCT:
+                out.append(self._PUNCT[t])
+            elif t < self.eot:
+                out.append(f" w{t}")
+        return "".join(out)
+
+    def encode(self, text, allowed_special=None):
+        import re
+        specials = {"<|en|>": 50259, "<|transcribe|>": self.transcribe, "<|translate|>": self.translate,
+                    "<|startofprev|>": self.sot_prev, "<|notimestamps|>": self.no_timestamps}
+        ids = []
+        for m in re.finditer(r"<\|[^|]*\|>|w(\d+)|,|-|>|\.", text):
+            tok = m.group(0)
+            if tok in specials:
+                ids.append(specials[tok])
+            elif tok.startswith("<|") and tok.endswith("|>"):
+                ids.append(self.timestamp_begin + int(round(float(tok[2:-2]) / 0.02)))     # <|t.tt|>
+            elif m.group(1):
+                ids.append(int(m.group(1)))
+            else:
+                ids.append({",": 11, "-": 12, ">": 13, ".": 14}[tok])
+        return ids

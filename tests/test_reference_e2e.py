@@ -1,0 +1,52 @@
+"""Host logic of whisper_amd.whisperer against outputs of the reference's own core.py (tests/golden/ref_e2e.json,
+made by tools/make_golden_e2e.py: urro_whisper.whisperer imported from the reference with its absent third-party
+modules replaced by oracle-backed stand-ins).  Here the same oracle sits behind the engine interface, so every
+difference is a difference in control flow: prompt construction, chunk loop and context carry-over, text filter,
+boundary-to-word mapping over ICU word breaks, forced-alignment windows and their merge."""
+import json
+import os
+
+import pytest
+
+from tests.helpers import WordTokenizer, synth_audio
+from tests.oracle_engine import OracleEngine
+from whisper_amd import align as A
+from whisper_amd import whisperer
+from whisper_amd.config import alignment_heads, alignment_heads_key, dims_for
+from whisper_amd.weights import synthetic_state_dict
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_e2e.json")
+CASES = {
+    "plain_two_chunks": dict(audio_seed=21, n_samples=16000 * 41, max_tokens=22),
+    "user_prompt": dict(audio_seed=22, n_samples=16000 * 12, max_tokens=30, prompt="w900 w901, w902"),
+    "hyphen_delimiter": dict(audio_seed=23, n_samples=16000 * 63, max_tokens=24, delimiter=" -"),
+    "forced_alignment": dict(audio_seed=24, n_samples=16000 * 47, max_tokens=448,
+                             transcript=" ".join(f"w{300 + i}" for i in range(26)) + ", w77."),
+}
+
+
+@pytest.fixture(scope="module")
+def engine():
+    gold = json.load(open(GOLD))
+    dims = dims_for(gold["model"])
+    sd = synthetic_state_dict(dims, seed=gold["weights"]["seed"], std=gold["weights"]["std"])
+    heads = alignment_heads(alignment_heads_key(gold["model"], dims.d_model, "en"), dims.dec_layers, dims.n_heads)
+    return gold, OracleEngine(dims, sd, heads, max_batch=2)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_whisperer_matches_reference_core(engine, name):
+    if not A._system_icu():
+        pytest.skip("the golden was made with ICU word breaks; no system ICU here")
+    gold, eng = engine
+    kw = dict(CASES[name])
+    audio = synth_audio(kw.pop("audio_seed"), kw.pop("n_samples"))
+    res = whisperer(model=gold["model"], audio=audio, language="en", tokenizer=WordTokenizer(), engine=eng, **kw)
+    ref = gold["cases"][name]
+    assert [int(t) for t in res["tokens"]] == ref["tokens"]
+    assert res["text"] == ref["text"]
+    assert res["language"] == ref["language"]
+    assert len(res["words"]) == len(ref["words"])
+    for got, exp in zip(res["words"], ref["words"]):
+        assert got["text"] == exp["text"]
+        assert got["start"] == exp["start"] and got["end"] == exp["end"], (got, exp)
