@@ -22,6 +22,8 @@ CASES = {
     "hyphen_delimiter": dict(audio_seed=23, n_samples=16000 * 63, max_tokens=24, delimiter=" -"),
     "forced_alignment": dict(audio_seed=24, n_samples=16000 * 47, max_tokens=448,
                              transcript=" ".join(f"w{300 + i}" for i in range(26)) + ", w77."),
+    "stream_hyphen": dict(audio_seed=25, n_samples=16000 * 38, max_tokens=20, delimiter=" -", stream=True),
+    "stream_plain": dict(audio_seed=26, n_samples=16000 * 33, max_tokens=16, stream=True),
 }
 
 
@@ -43,6 +45,9 @@ def test_whisperer_matches_reference_core(engine, name):
     audio = synth_audio(kw.pop("audio_seed"), kw.pop("n_samples"))
     res = whisperer(model=gold["model"], audio=audio, language="en", tokenizer=WordTokenizer(), engine=eng, **kw)
     ref = gold["cases"][name]
+    if kw.get("stream"):
+        assert list(res) == ref["pieces"]
+        return
     assert [int(t) for t in res["tokens"]] == ref["tokens"]
     assert res["text"] == ref["text"]
     assert res["language"] == ref["language"]

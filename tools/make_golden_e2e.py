@@ -150,6 +150,8 @@ def cases():
         "hyphen_delimiter": dict(audio_seed=23, n_samples=16000 * 63, max_tokens=24, delimiter=" -"),
         "forced_alignment": dict(audio_seed=24, n_samples=16000 * 47, max_tokens=448,
                                  transcript=" ".join(f"w{300 + i}" for i in range(26)) + ", w77."),
+        "stream_hyphen": dict(audio_seed=25, n_samples=16000 * 38, max_tokens=20, delimiter=" -", stream=True),
+        "stream_plain": dict(audio_seed=26, n_samples=16000 * 33, max_tokens=16, stream=True),
     }
 
 
@@ -168,6 +170,11 @@ def main():
         audio = synth_audio(kw.pop("audio_seed"), kw.pop("n_samples"))
         res = urro_whisper.whisperer(model=MODEL, audio=audio, language="en", onnx_encoder=enc_p, onnx_decoder=dec_p,
                                      onnx_providers=["CPUExecutionProvider"], **kw)
+        if kw.get("stream"):
+            pieces = list(res)
+            out["cases"][name] = {"pieces": pieces}
+            print(name, "pieces", len(pieces))
+            continue
         out["cases"][name] = {"text": res["text"], "tokens": [int(t) for t in res["tokens"]], "words": res["words"],
                               "language": res.get("language")}
         timed = sum(1 for w in res["words"] if w.get("start") is not None)
