@@ -124,3 +124,33 @@ def test_whisperer_delimiter_stream_and_transcript_modes():
     assert al["words"] and all(w["start"] is not None and 0 <= w["start"] <= len(audio) / 16000 + 30 for w in al["words"])
     assert [w["start"] for w in al["words"]] == sorted(w["start"] for w in al["words"])
     eng.close()
+
+
+def test_whisperer_on_gpu_reproduces_reference_core_golden():
+    """fp32 engine on the golden made from the reference's own core.py (tests/golden/ref_e2e.json): identical tokens
+    and text, every word time within one 20 ms frame (measured: equal)."""
+    import json
+    import os
+    from tests.helpers import WordTokenizer
+    from tests.test_reference_e2e import CASES, GOLD
+    from whisper_amd import engine as E
+    from whisper_amd.config import alignment_heads, alignment_heads_key
+    gold = json.load(open(GOLD))
+    dims = dims_for(gold["model"])
+    sd = synthetic_state_dict(dims, seed=gold["weights"]["seed"], std=gold["weights"]["std"])
+    heads = alignment_heads(alignment_heads_key(gold["model"], dims.d_model, "en"), dims.dec_layers, dims.n_heads)
+    eng = E.Engine(dims, sd, dtype="f32", max_batch=2, align_heads=heads)
+    try:
+        for name in ("plain_two_chunks", "user_prompt", "hyphen_delimiter", "forced_alignment"):
+            kw = dict(CASES[name])
+            audio = synth_audio(kw.pop("audio_seed"), kw.pop("n_samples"))
+            res = whisperer(model=gold["model"], audio=audio, language="en", tokenizer=WordTokenizer(), engine=eng, **kw)
+            ref = gold["cases"][name]
+            assert [int(t) for t in res["tokens"]] == ref["tokens"], name
+            assert res["text"] == ref["text"]
+            assert [w["text"] for w in res["words"]] == [w["text"] for w in ref["words"]]
+            close = [abs(g["start"] - e["start"]) <= 0.0201 and abs(g["end"] - e["end"]) <= 0.0201
+                     for g, e in zip(res["words"], ref["words"]) if e["start"] is not None]
+            assert all(close), (name, sum(close), len(close))
+    finally:
+        eng.close()
