@@ -516,7 +516,8 @@ template <typename T, typename TC> int launch_big(const GemmParams& p, hipStream
 // are combined through LDS in a fixed order (results are run-to-run identical).  Activations (<= 128 rows)
 // stay L2-resident and are read as MFMA fragments straight from global memory.
 constexpr int SK_WAVES = 8;
-constexpr int SK_ROUND = 2;   // K-steps per register buffer; two buffers are in flight
+constexpr int SK_ROUND = 3;      // K-steps per register buffer; two buffers are in flight
+constexpr int SK_ROUND_LN = 2;   // same for the LayerNorm-fused form, whose f32 operand takes twice the registers
 
 template <typename T, typename TC, int MT, int NT, bool PACKED>
 __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p)
@@ -724,10 +725,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_step_ln_kernel(GemmParams 
     auto ld = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) -> uint4 {
         return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
     };
-    uint4 wv[2][SK_ROUND][NT], xv[2][SK_ROUND][MT][AH];
+    uint4 wv[2][SK_ROUND_LN][NT], xv[2][SK_ROUND_LN][MT][AH];
     auto load_round = [&](int buf, int s) {
 #pragma unroll
-        for (int r = 0; r < SK_ROUND; ++r) {
+        for (int r = 0; r < SK_ROUND_LN; ++r) {
             const int st = min(s + r, s_end - 1);   // steps past the end re-read the last one (unused)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wv[buf][r][nt] = ld(rsW, woff[nt], st * 1024);
@@ -739,7 +740,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_step_ln_kernel(GemmParams 
     };
     auto mma_round = [&](int buf, int s) {
 #pragma unroll
-        for (int r = 0; r < SK_ROUND; ++r) {
+        for (int r = 0; r < SK_ROUND_LN; ++r) {
             if (s + r < s_end) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -777,15 +778,15 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_step_ln_kernel(GemmParams 
     };
     if (s_begin < s_end) {
         load_round(0, s_begin);
-        for (int s = s_begin; s < s_end; s += 2 * SK_ROUND) {
-            if (s + SK_ROUND < s_end) load_round(1, s + SK_ROUND);
+        for (int s = s_begin; s < s_end; s += 2 * SK_ROUND_LN) {
+            if (s + SK_ROUND_LN < s_end) load_round(1, s + SK_ROUND_LN);
             __builtin_amdgcn_sched_barrier(0);
             mma_round(0, s);
             __builtin_amdgcn_sched_barrier(0);
-            if (s + SK_ROUND < s_end) {
-                if (s + 2 * SK_ROUND < s_end) load_round(0, s + 2 * SK_ROUND);
+            if (s + SK_ROUND_LN < s_end) {
+                if (s + 2 * SK_ROUND_LN < s_end) load_round(0, s + 2 * SK_ROUND_LN);
                 __builtin_amdgcn_sched_barrier(0);
-                mma_round(1, s + SK_ROUND);
+                mma_round(1, s + SK_ROUND_LN);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
