@@ -82,3 +82,39 @@ def test_one_real_size_window_matches_oracle_fp32(small):
             assert np.abs(rows - np.stack([rows_ref[l][0, h] for l, h in heads])).max() < 1e-5
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("model,B", [("medium", 6), ("large-v3-turbo", 8)])
+def test_largest_shapes_run_and_are_batch_invariant(model, B):
+    """The two largest configurations at their real depth (24 + 24 layers at d = 1024; 32 + 4 layers at d = 1280 with
+    128 mel bins), bf16: duplicated windows agree bit for bit, rows are probability rows, boundaries monotone."""
+    dims = dims_for(model)
+    sd = synthetic_state_dict(dims, seed=1)
+    heads = alignment_heads(alignment_heads_key(model, dims.d_model, "en"), dims.dec_layers, dims.n_heads)
+    eng = E.Engine(dims, sd, dtype="bf16", max_batch=B, align_heads=heads)
+    del sd
+    try:
+        base = [synth_audio(60), synth_audio(61, 300000)]
+        order = [i % 2 for i in range(B)]
+        buf = np.zeros((B, 480000), np.float32)
+        for b, i in enumerate(order):
+            buf[b, : len(base[i])] = base[i]
+        n_samples = torch.tensor([len(base[i]) for i in order], dtype=torch.int32)
+        prompt = [SP["sot"], 50259, 50359, SP["ts_begin"]]
+        res = eng.transcribe_windows(torch.from_numpy(buf).to(DEV), n_samples, [prompt] * B, len(prompt) + 10, SP["eot"], SP["sot"],
+                                     SP["ts_begin"], SP["ts_end"])
+        n_text = res["n_text"].cpu().numpy()
+        assert (res["n_new"].cpu().numpy() == 10).all()
+        toks, bnd = res["new_tokens"].cpu().numpy(), res["boundaries"].cpu().numpy()
+        rows = eng.attn_rows(B, int(max(1, n_text.max()))).cpu().numpy()
+        for b in range(2, B):
+            assert np.array_equal(toks[b], toks[b % 2]) and np.array_equal(bnd[b], bnd[b % 2])
+            assert np.array_equal(rows[b, :, : n_text[b]], rows[b % 2, :, : n_text[b]])
+        for b in range(2):
+            nt = int(n_text[b])
+            if nt:
+                assert np.allclose(rows[b, :, :nt].sum(-1), 1.0, atol=2e-3)
+                bd = bnd[b, : nt + 1]
+                assert bd[0] == 0 and np.all(np.diff(bd) >= 0) and bd[-1] <= 1500
+    finally:
+        eng.close()
