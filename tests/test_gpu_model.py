@@ -175,3 +175,26 @@ def test_transcribe_windows_end_to_end(micro):
         bd = res["boundaries"][b, : nt + 1].cpu().numpy()
         assert bd[0] == 0 and np.all(np.diff(bd) >= 0) and bd[-1] <= 1500
         assert bd[-1] == bd[-2]        # the reference's length fix-up repeats the last boundary
+
+
+def test_batches_beyond_128_windows_decode_in_chunks():
+    """The decode step's products take at most 128 rows per launch; 160 windows must give what 2 windows give."""
+    dims = CFG.dims_for("micro")
+    sd = synthetic_state_dict(dims, seed=0, std=0.06)
+    B = 160
+    eng = E.Engine(dims, sd, dtype="f32", max_batch=B, align_heads=HEADS)
+    try:
+        base = [synth_audio(1), synth_audio(2, 300000)]
+        buf = np.zeros((B, 480000), np.float32)
+        for b in range(B):
+            buf[b, : len(base[b % 2])] = base[b % 2]
+        n = torch.tensor([len(base[b % 2]) for b in range(B)], dtype=torch.int32)
+        sp = MICRO_SPECIALS
+        res = eng.transcribe_windows(torch.from_numpy(buf).to(DEV), n, [[824, 825, 826, 924]] * B, 16, sp["eot"], sp["sot"],
+                                     sp["ts_begin"], sp["ts_end"])
+        toks, bnd = res["new_tokens"].cpu().numpy(), res["boundaries"].cpu().numpy()
+        assert (res["n_new"].cpu().numpy() == 12).all()
+        for b in range(2, B):
+            assert np.array_equal(toks[b], toks[b % 2]) and np.array_equal(bnd[b], bnd[b % 2]), b
+    finally:
+        eng.close()

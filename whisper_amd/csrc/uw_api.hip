@@ -566,9 +566,17 @@ __global__ void embed_step_kernel(float* __restrict__ x, const float* __restrict
     for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) *(f32x4*)(x + x_elem_offset<T>(b, i * 4, d)) = e[i] + pe[i];
 }
 
+int decoder_step_chunk(uw_ctx* c, int b0, int B, hipStream_t s);
 // one KV-cached decoder step for the token at st_pos[b] of windows [b0, b0 + B) -> their rows of c->logits.
-// Every buffer is indexed by window, so disjoint window ranges can run on different streams concurrently.
+// The step's products take at most 128 rows per launch: larger batches go through in chunks of 128 windows.
 int decoder_step(uw_ctx* c, int b0, int B, hipStream_t s)
+{
+    for (int off = 0; off < B; off += 128) RUN(decoder_step_chunk(c, b0 + off, std::min(128, B - off), s));
+    return UW_OK;
+}
+
+// Every buffer is indexed by window, so disjoint window ranges (starting on multiples of 16) are independent.
+int decoder_step_chunk(uw_ctx* c, int b0, int B, hipStream_t s)
 {
     const int d = c->d, S = c->S, H = c->H, Tm = c->Tm;
     const size_t es = c->es;
