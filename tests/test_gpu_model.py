@@ -198,3 +198,33 @@ def test_batches_beyond_128_windows_decode_in_chunks():
             assert np.array_equal(toks[b], toks[b % 2]) and np.array_equal(bnd[b], bnd[b % 2]), b
     finally:
         eng.close()
+
+
+def test_cross_attention_decode_forms_agree(micro):
+    """The one-workgroup-per-(window, head) form (what full batches run) and the row-split form (small batches) of the
+    cross-attention decode step: same tokens, rows within 1e-6 of each other and of the oracle."""
+    import os
+    om, enc = micro["om"], micro["enc"]
+    sp = dict(MICRO_SPECIALS, sot=700)
+    prompts = [[824, 825, 826, 924], [823, 5, 6, 7, 824, 825, 826, 924, 11, 12]]
+    got = {}
+    for mode in ("0", "3", "8"):
+        os.environ["UW_DECODE_SPLIT"] = mode
+        try:
+            eng = E.Engine(micro["dims"], micro["sd"], dtype="f32", max_batch=2, align_heads=HEADS)
+        finally:
+            del os.environ["UW_DECODE_SPLIT"]
+        try:
+            eng.cross_kv(2, torch.from_numpy(enc).to(DEV))
+            res = eng.decode_greedy(prompts, 30, sp["eot"], sp["sot"], sp["ts_begin"], sp["ts_end"])
+            nt = res["n_text"].cpu().numpy()
+            got[mode] = (res["new_tokens"].cpu().numpy(), nt, eng.attn_rows(2, int(nt.max())).cpu().numpy())
+        finally:
+            eng.close()
+    new, text, rows_ref = _reference_window(om, enc[:1], prompts[0], 30, sp)
+    for mode in ("0", "3", "8"):
+        toks, nt, rows = got[mode]
+        assert np.array_equal(toks, got["0"][0]) and np.array_equal(nt, got["0"][1])
+        assert toks[0, : len(new)].tolist() == new
+        assert np.abs(rows - got["0"][2]).max() < 1e-6
+        assert np.abs(rows[0, :, : len(text)] - np.stack([rows_ref[l][0, h] for l, h in HEADS])).max() < 1e-6

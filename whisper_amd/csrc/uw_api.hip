@@ -95,6 +95,8 @@ struct uw_ctx {
     hipEvent_t sub_event[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork_event = nullptr;
     int n_streams = 4;
+    int split_mode = -1;           // cross-attention decode: -1 choose by grid size, 0 never split, n > 1 always n parts
+    float* split_ws = nullptr;
 };
 
 namespace {
@@ -306,6 +308,9 @@ int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
 int create_streams(uw_ctx* c)
 {
     const char* env = getenv("UW_DECODE_STREAMS");
+    const char* sp = getenv("UW_DECODE_SPLIT");   // development / test knob: force the row-split form on or off
+    c->split_mode = sp ? atoi(sp) : -1;
+    if (c->split_mode > 16) c->split_mode = 16;
     c->n_streams = env ? atoi(env) : 1;   // concurrent queues did not overlap on MI355X (measured): one stream by default
     if (c->n_streams < 1) c->n_streams = 1;
     if (c->n_streams > 4) c->n_streams = 4;
@@ -344,6 +349,7 @@ int alloc_workspace(uw_ctx* c)
     ALLOC(c->d_attn, Bm * Tm * d * es, true);
     ALLOC(c->d_mlp, Bm * Tm * 4 * d * es, true);
     ALLOC(c->d_last, Bm * d * 4, true);
+    ALLOC(c->split_ws, Bm * (d / 64) * 16 * 66 * 4, true);
     c->logits_ld = (c->V + 3) & ~3;
     ALLOC(c->logits, Bm * c->logits_ld * 4, true);
     if (c->n_sel > 0) {
@@ -614,6 +620,9 @@ int decoder_step_chunk(uw_ctx* c, int b0, int B, hipStream_t s)
             if (c->cfg.align_layer[k] == (int)li) cp.sel_slot[c->cfg.align_head[k]] = k;
         cp.out_packed = 1; cp.B = B; cp.H = H; cp.d = d; cp.S = S; cp.n_rows_max = Tm; cp.ld_kv = 64;
         cp.kv_sB = (long)S * 2 * d; cp.kv_sH = (long)S * 64;
+        // a handful of (window, head) pairs (single-window use): cut the frames over several workgroups
+        cp.n_split = c->split_mode >= 0 ? std::max(1, c->split_mode) : (H * B >= 64 ? 1 : 8);
+        cp.split_ws = c->split_ws + (long)b0 * H * 16 * 66;
         const bool timed = c->prof_on && c->prof_used + 2 <= c->prof_ev.size();
         if (timed) UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used], s));
         RUN(uw_cross_attn_decode(c->dt, cp, s));

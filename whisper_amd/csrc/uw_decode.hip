@@ -58,16 +58,17 @@ template <typename T> __device__ __forceinline__ float row_sum(float v)
 }
 
 // ------------------------------------------------------------------------------------------------
-// cross-attention for one new token: grid (H, B), 256 threads
-template <typename T>
-__global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
+// cross-attention for one new token: grid (H, B), NW waves per workgroup (4 when the grid fills the chip several
+// times over, more when it does not: the bytes in flight per CU are what covers the HBM latency)
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void cross_decode_kernel(CrossDecodeParams p)
 {
     using R = Row<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sc = (float*)smem;                 // [S rounded up] scores, then probabilities
     const int S = p.S, Spad = (S + 63) & ~63;
-    float* red = sc + Spad;                   // [8]
-    float* part = red + 8;                    // [4 waves][64]
+    float* red = sc + Spad;                   // [2 * NW]
+    float* part = red + 2 * NW;               // [NW waves][64]
     const int h = blockIdx.x, b = blockIdx.y;
     if (p.active && !p.active[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,17 +85,17 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
     }
     // ---- scores ----
     constexpr int U = 8;                               // loads in flight per lane
-    const int rows_per_round = 4 * R::RPI * U;         // rows covered by the workgroup per unrolled round
+    const int rows_per_round = NW * R::RPI * U;         // rows covered by the workgroup per unrolled round
     for (int r0 = 0; r0 < S; r0 += rows_per_round) {
         uint4 kv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            const int r = r0 + (u * NW + wave) * R::RPI + rin;
             kv[u] = ld_stream(Kh + (long)min(r, S - 1) * ld);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            const int r = r0 + (u * NW + wave) * R::RPI + rin;
             const float s = row_sum<T>(dot_chunk<T>(kv[u], q));
             if (sub == 0 && r < S) sc[r] = s;
         }
@@ -103,34 +104,39 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
     uint4 vv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        const int r = (u * 4 + wave) * R::RPI + rin;
+        const int r = (u * NW + wave) * R::RPI + rin;
         vv[u] = ld_stream(Vh + (long)min(r, S - 1) * ld);
     }
     __syncthreads();
     // ---- softmax over S ----
     float mx = -INFINITY;
-    for (int j = tid; j < S; j += 256) mx = fmaxf(mx, sc[j]);
+    for (int j = tid; j < S; j += 64 * NW) mx = fmaxf(mx, sc[j]);
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
     __syncthreads();
-    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w]);
     float sum = 0.f;
-    for (int j = tid; j < S; j += 256) {
+    for (int j = tid; j < S; j += 64 * NW) {
         const float e = __expf(sc[j] - mx);
         sc[j] = e;
         sum += e;
     }
     sum = wave_sum(sum);
-    if (lane == 0) red[4 + wave] = sum;
+    if (lane == 0) red[NW + wave] = sum;
     __syncthreads();
-    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red[NW + w];
+    const float inv = 1.0f / tot;
     const int slot = p.sel_slot[h];
     float* row_out = nullptr;
     if (p.rows && slot >= 0) {
         const int ri = p.row_index[b];
         if (ri >= 0 && ri < p.n_rows_max) row_out = p.rows + (long)b * p.rows_sB + (long)slot * p.rows_sSel + (long)ri * S;
     }
-    for (int j = tid; j < S; j += 256) {
+    for (int j = tid; j < S; j += 64 * NW) {
         const float pr = sc[j] * inv;
         sc[j] = pr;
         if (row_out) row_out[j] = pr;
@@ -144,13 +150,13 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
         if (r0 > 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+                const int r = r0 + (u * NW + wave) * R::RPI + rin;
                 vv[u] = ld_stream(Vh + (long)min(r, S - 1) * ld);
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            const int r = r0 + (u * NW + wave) * R::RPI + rin;
             const float w = (r < S) ? sc[r] : 0.f;
             float f[R::E];
             unpack<T>(vv[u], f);
@@ -170,9 +176,148 @@ __global__ __launch_bounds__(256) void cross_decode_kernel(CrossDecodeParams p)
     }
     __syncthreads();
     if (tid < 64) {
-        const float o = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+        float o = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) o += part[w * 64 + tid];
         const long at = p.out_packed ? frag_elem_offset<T>(b, h * 64 + tid, p.d) : (long)b * p.d + h * 64 + tid;
         ((T*)p.out)[at] = from_f32<T>(o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small batches: (H, B) workgroups cannot fill 256 CUs, so the 1500 rows of a (window, head) are cut over
+// n_split workgroups.  Each leaves (local max, local exp-sum, 64 unnormalised accumulators) and, for an alignment
+// head, its raw scores in the rows buffer; the combine pass merges the parts and turns the scores into
+// probabilities.  grid (H, B, n_split), 256 threads.
+template <typename T>
+__global__ __launch_bounds__(256) void cross_decode_split_kernel(CrossDecodeParams p)
+{
+    using R = Row<T>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sc = (float*)smem;                 // [rows of this part, rounded up]
+    const int h = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
+    if (p.active && !p.active[b]) return;
+    const int per = (((p.S + p.n_split - 1) / p.n_split) + 31) & ~31;   // rows per part, a multiple of 32
+    const int s0 = z * per, S = min(p.S - s0, per);                      // this part: rows [s0, s0 + S)
+    float* red = sc + per;                    // [8]
+    float* part = red + 8;                    // [4 waves][64]
+    float* ws = p.split_ws + (((long)b * p.H + h) * p.n_split + z) * 66;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (S <= 0) {
+        if (tid < 66) ws[tid] = tid == 0 ? -INFINITY : 0.f;
+        return;
+    }
+    const int sub = lane % R::LPR, rin = lane / R::LPR;
+    const long ld = p.ld_kv;
+    const T* Kh = (const T*)p.K + (long)b * p.kv_sB + (long)h * p.kv_sH + (long)s0 * ld + sub * R::E;
+    const T* Vh = (const T*)p.V + (long)b * p.kv_sB + (long)h * p.kv_sH + (long)s0 * ld + sub * R::E;
+    float q[R::E];
+    {
+        const T* qp = (const T*)p.q + (long)b * p.d + h * 64 + sub * R::E;
+#pragma unroll
+        for (int e = 0; e < R::E; ++e) q[e] = to_f32<T>(qp[e]);
+    }
+    constexpr int U = 8;
+    const int rows_per_round = 4 * R::RPI * U;
+    for (int r0 = 0; r0 < S; r0 += rows_per_round) {
+        uint4 kv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            kv[u] = ld_stream(Kh + (long)min(r, S - 1) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            const float s = row_sum<T>(dot_chunk<T>(kv[u], q));
+            if (sub == 0 && r < S) sc[r] = s;
+        }
+    }
+    __syncthreads();
+    const int slot = p.sel_slot[h];
+    float* row_out = nullptr;
+    if (p.rows && slot >= 0) {
+        const int ri = p.row_index[b];
+        if (ri >= 0 && ri < p.n_rows_max) row_out = p.rows + (long)b * p.rows_sB + (long)slot * p.rows_sSel + (long)ri * p.S + s0;
+    }
+    float mx = -INFINITY;
+    for (int j = tid; j < S; j += 256) {
+        mx = fmaxf(mx, sc[j]);
+        if (row_out) row_out[j] = sc[j];      // raw score; the combine pass makes it a probability
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int j = tid; j < S; j += 256) {
+        const float e = __expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    float acc[R::E];
+#pragma unroll
+    for (int e = 0; e < R::E; ++e) acc[e] = 0.f;
+    for (int r0 = 0; r0 < S; r0 += rows_per_round) {
+        uint4 vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            vv[u] = ld_stream(Vh + (long)min(r, S - 1) * ld);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+            const float w = (r < S) ? sc[r] : 0.f;
+            float f[R::E];
+            unpack<T>(vv[u], f);
+#pragma unroll
+            for (int e = 0; e < R::E; ++e) acc[e] = fmaf(w, f[e], acc[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < R::E; ++e) {
+#pragma unroll
+        for (int o = R::LPR; o < 64; o <<= 1) acc[e] += __shfl_xor(acc[e], o, 64);
+    }
+    if (rin == 0) {
+#pragma unroll
+        for (int e = 0; e < R::E; ++e) part[wave * 64 + sub * R::E + e] = acc[e];
+    }
+    __syncthreads();
+    if (tid < 64) ws[2 + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+    if (tid == 64) ws[0] = mx;
+    if (tid == 65) ws[1] = (red[4] + red[5]) + (red[6] + red[7]);
+}
+
+// merges the parts of one (window, head) in part order; grid (H, B), 256 threads
+template <typename T>
+__global__ __launch_bounds__(256) void cross_combine_kernel(CrossDecodeParams p)
+{
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (p.active && !p.active[b]) return;
+    const float* ws = p.split_ws + ((long)b * p.H + h) * p.n_split * 66;
+    float M = -INFINITY;
+    for (int z = 0; z < p.n_split; ++z) M = fmaxf(M, ws[z * 66]);
+    float L = 0.f;
+    for (int z = 0; z < p.n_split; ++z) L += ws[z * 66 + 1] * __expf(ws[z * 66] - M);
+    const float inv = 1.0f / L;
+    if (tid < 64) {
+        float o = 0.f;
+        for (int z = 0; z < p.n_split; ++z) o += ws[z * 66 + 2 + tid] * __expf(ws[z * 66] - M);
+        const long at = p.out_packed ? frag_elem_offset<T>(b, h * 64 + tid, p.d) : (long)b * p.d + h * 64 + tid;
+        ((T*)p.out)[at] = from_f32<T>(o * inv);
+    }
+    const int slot = p.sel_slot[h];
+    if (p.rows && slot >= 0) {
+        const int ri = p.row_index[b];
+        if (ri >= 0 && ri < p.n_rows_max) {
+            float* row = p.rows + (long)b * p.rows_sB + (long)slot * p.rows_sSel + (long)ri * p.S;
+            for (int j = tid; j < p.S; j += 256) row[j] = __expf(row[j] - M) * inv;
+        }
     }
 }
 
@@ -316,10 +461,32 @@ int uw_cross_attn_decode(int dtype, const CrossDecodeParams& p, hipStream_t s)
     UW_REQUIRE(p.q && p.K && p.V && p.out && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.S > 0 && p.S <= 4096 && p.ld_kv >= 64,
                "cross_attn_decode: bad arguments");
     UW_REQUIRE(!p.rows || p.row_index, "cross_attn_decode: rows without row_index");
-    const size_t lds = (size_t)(((p.S + 63) & ~63) + 8 + 256) * 4;
+    if (p.n_split > 1) {
+        UW_REQUIRE(p.split_ws && p.n_split <= 16, "cross_attn_decode: split needs a workspace and at most 16 parts");
+        const int per = (((p.S + p.n_split - 1) / p.n_split) + 31) & ~31;
+        const size_t lds = (size_t)(per + 8 + 256) * 4;
+        const dim3 grid(p.H, p.B, p.n_split), grid2(p.H, p.B);
+        if (dtype == UW_F32) {
+            hipLaunchKernelGGL(cross_decode_split_kernel<float>, grid, dim3(256), lds, s, p);
+            hipLaunchKernelGGL(cross_combine_kernel<float>, grid2, dim3(256), 0, s, p);
+        } else {
+            hipLaunchKernelGGL(cross_decode_split_kernel<bf16_t>, grid, dim3(256), lds, s, p);
+            hipLaunchKernelGGL(cross_combine_kernel<bf16_t>, grid2, dim3(256), 0, s, p);
+        }
+        UW_LAUNCH_CHECK();
+        return UW_OK;
+    }
     const dim3 grid(p.H, p.B);
-    if (dtype == UW_F32) hipLaunchKernelGGL(cross_decode_kernel<float>, grid, dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(cross_decode_kernel<bf16_t>, grid, dim3(256), lds, s, p);
+    const int wgs = p.H * p.B;
+#define UW_CROSS_LAUNCH(NW)                                                                                     \
+    do {                                                                                                        \
+        const size_t lds = (size_t)(((p.S + 63) & ~63) + 2 * NW + NW * 64) * 4;                                 \
+        if (dtype == UW_F32) hipLaunchKernelGGL((cross_decode_kernel<float, NW>), grid, dim3(64 * NW), lds, s, p); \
+        else hipLaunchKernelGGL((cross_decode_kernel<bf16_t, NW>), grid, dim3(64 * NW), lds, s, p);               \
+    } while (0)
+    if (wgs >= 512) UW_CROSS_LAUNCH(4);    // measured: 640 workgroups are faster with 4 waves, 256 with 16
+    else UW_CROSS_LAUNCH(16);
+#undef UW_CROSS_LAUNCH
     UW_LAUNCH_CHECK();
     return UW_OK;
 }
