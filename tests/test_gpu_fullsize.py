@@ -67,19 +67,23 @@ def test_one_real_size_window_matches_oracle_fp32(small):
     max_tokens = len(prompt) + 5
     new = O.greedy_reference_schedule(om, enc_ref, prompt, max_tokens, SP["eot"])
     text = O.filter_text_tokens(new, SP["sot"], SP["ts_begin"], SP["ts_end"])
-    eng = E.Engine(dims, sd, dtype="f32", max_batch=2, align_heads=heads)
+    # 44 copies of the window: 44 x 12 heads = 528 (window, head) pairs, which selects the decode-attention form
+    # that full batches run (4 waves per workgroup); every copy must match the oracle
+    B = 44
+    eng = E.Engine(dims, sd, dtype="f32", max_batch=B, align_heads=heads)
     try:
         enc = eng.encode(torch.from_numpy(mel).to(DEV)).cpu().numpy()
         assert np.abs(enc - enc_ref).max() < 5e-4, np.abs(enc - enc_ref).max()
-        res = eng.transcribe_windows(torch.from_numpy(a[None]).to(DEV), torch.tensor([480000], dtype=torch.int32), [prompt],
-                                     max_tokens, SP["eot"], SP["sot"], SP["ts_begin"], SP["ts_end"])
-        nn, nt = int(res["n_new"][0]), int(res["n_text"][0])
-        assert res["new_tokens"][0, :nn].cpu().tolist() == new
-        assert res["text_ids"][0, :nt].cpu().tolist() == text
-        if text:
-            rows_ref = O.attention_rows_reference_schedule(om, enc_ref, prompt, text)
-            rows = eng.attn_rows(1, nt)[0].cpu().numpy()
-            assert np.abs(rows - np.stack([rows_ref[l][0, h] for l, h in heads])).max() < 1e-5
+        res = eng.transcribe_windows(torch.from_numpy(np.repeat(a[None], B, 0)).to(DEV), torch.full((B,), 480000, dtype=torch.int32),
+                                     [prompt] * B, max_tokens, SP["eot"], SP["sot"], SP["ts_begin"], SP["ts_end"])
+        rows_ref = O.attention_rows_reference_schedule(om, enc_ref, prompt, text) if text else None
+        for b in (0, 17, B - 1):
+            nn, nt = int(res["n_new"][b]), int(res["n_text"][b])
+            assert res["new_tokens"][b, :nn].cpu().tolist() == new
+            assert res["text_ids"][b, :nt].cpu().tolist() == text
+            if text:
+                rows = eng.attn_rows(B, nt)[b].cpu().numpy()
+                assert np.abs(rows - np.stack([rows_ref[l][0, h] for l, h in heads])).max() < 1e-5
     finally:
         eng.close()
 
