@@ -264,8 +264,8 @@ int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
     // shift into the bias, plus the row sums the kernel needs for the mean.
     {
         const long f = 4 * d;
-        void* tmp = nullptr;
-        UW_HIP_CHECK(hipMalloc(&tmp, (size_t)f * d * c->es));
+        void* tmp = nullptr;   // row-major staging for the folded weights; owned by the context like every other buffer
+        ALLOC(tmp, (size_t)f * d * c->es, false);
         for (auto& l : c->dec) {
             ALLOC(l.self.wqkv_p, 3 * d * d * c->es, false);
             ALLOC(l.self.wo_p, d * d * c->es, false);
@@ -293,8 +293,6 @@ int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
             RUN(uw_pack_frag(c->dt, l.cross.wo, d, l.cross.wo_p, (int)d, (int)d, 0));
             RUN(uw_pack_frag(c->dt, l.w2, f, l.w2_p, (int)d, (int)f, 0));
         }
-        UW_HIP_CHECK(hipDeviceSynchronize());
-        UW_HIP_CHECK(hipFree(tmp));
     }
     const float *dlg = cur.next(), *dlb = cur.next();
     ALLOC(c->dec_ln_g, d * 4, false);
