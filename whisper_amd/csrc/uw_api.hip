@@ -719,6 +719,10 @@ int check_batch(uw_ctx* c, int B)
 {
     UW_REQUIRE(c, "null context");
     UW_REQUIRE(B > 0 && B <= c->Bm, "batch %d outside 1..max_batch=%d", B, c->Bm);
+    // a context lives on the device that was current when it was created; make it current for this call as well
+    int dev = -1;
+    UW_HIP_CHECK(hipGetDevice(&dev));
+    if (dev != c->device) UW_HIP_CHECK(hipSetDevice(c->device));
     return UW_OK;
 }
 
