@@ -55,3 +55,13 @@ def test_whisperer_matches_reference_core(engine, name):
     for got, exp in zip(res["words"], ref["words"]):
         assert got["text"] == exp["text"]
         assert got["start"] == exp["start"] and got["end"] == exp["end"], (got, exp)
+
+
+def test_delimiter_factories_match_reference():
+    from whisper_amd import delimiters as D
+    gold = json.load(open(GOLD))["delimiters"]
+    for name, exp in gold.items():
+        f = getattr(D, name)
+        assert f.regex == exp["regex"] and f() == exp["default"]
+    assert D.HYPHEN(3) == gold["HYPHEN"]["count3"]
+    assert D.SPEAKER("(", True) == gold["SPEAKER"]["paren_short"] and D.PERSON("<") == gold["PERSON"]["angle"]

@@ -179,6 +179,11 @@ def main():
                               "language": res.get("language")}
         timed = sum(1 for w in res["words"] if w.get("start") is not None)
         print(name, "tokens", len(res["tokens"]), "words", len(res["words"]), "timed", timed)
+    from urro_whisper import delimiters as RD
+    out["delimiters"] = {n: {"regex": getattr(RD, n).regex, "default": getattr(RD, n)()} for n in ("HYPHEN", "GREATER_THAN", "SPEAKER", "PERSON")}
+    out["delimiters"]["HYPHEN"]["count3"] = RD.HYPHEN(3)
+    out["delimiters"]["SPEAKER"]["paren_short"] = RD.SPEAKER("(", True)
+    out["delimiters"]["PERSON"]["angle"] = RD.PERSON("<")
     with open(os.path.join(GOLD, "ref_e2e.json"), "w") as f:
         json.dump(out, f, indent=1)
 
