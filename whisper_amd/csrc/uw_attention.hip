@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int i = 0; i < L::NQ; ++i) qf[i] = *(const uint4*)(qrow + (2 * i + hl) * L::E);
     }
+    retire_vector_loads();   // otherwise every loop iteration waits on vmcnt for Q, and with it for the DMA just issued
 
     int n_tiles = (Sk + 63) / 64;
     if (causal) {

@@ -58,6 +58,26 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr)
                  : "memory");
 }
 
+// Same DMA with the address split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset.
+// hipcc tracks the VGPR inputs of an asm statement as pending until vmcnt retires them; a per-lane 64-bit address
+// recomputed every iteration lives in temporaries that the next ds_read overwrites, so the compiler inserts a
+// vmcnt(0) there and the ring loses its prefetch.  With this form the only VGPR input is a loop-invariant offset
+// that is never overwritten; the advancing part of the address lives in SGPRs.
+__device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsigned lds_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+
+// s_waitcnt vmcnt(0) that the COMPILER sees (expcnt and lgkmcnt left alone).  Ordinary loads issued before a loop
+// whose first use is inside the loop make hipcc place a vmcnt wait at that use in every iteration -- and since it
+// does not count the asm-issued LDS DMAs, that wait is vmcnt(0) and drains the ring each time round.  Retiring
+// such loads with this builtin in front of the loop removes the in-loop waits.
+__device__ __forceinline__ void retire_vector_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  This bijection hands each
 // XCD a CONTIGUOUS run of tile indices, so tiles that share an operand panel hit the same L2 (speed only).
 __device__ __forceinline__ int xcd_contiguous_tile(int b, int nwg)

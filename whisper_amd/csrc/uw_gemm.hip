@@ -333,25 +333,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const T* __restrict__ A = (const T*)p.A + bz * p.sA;
     const T* __restrict__ B = (const T*)p.B + bz * p.sB;
 
-    // one DMA instruction of a wave fills 16 rows x 64 bytes; lane -> (row, position), source chunk = position ^ g(row)
-    const T* srcA[2];
-    const T* srcB;
+    // one DMA instruction of a wave fills 16 rows x 64 bytes; lane -> (row, position), source chunk = position ^ g(row).
+    // Per-lane byte offsets inside the tile are loop-invariant; tile origin and K position go into the scalar base.
+    unsigned offA[2], offB;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int L = i * 512 + tid, row = L >> 2, c = (L & 3) ^ ((-(row >> 2)) & 3);
-        srcA[i] = A + (long)min(m0 + row, p.M - 1) * p.lda + c * E;
+        offA[i] = (unsigned)(((long)(min(m0 + row, p.M - 1) - m0) * p.lda + c * E) * (long)sizeof(T));
     }
     {
         const int row = tid >> 2, c = (tid & 3) ^ ((-(row >> 2)) & 3);
-        srcB = B + (long)min(n0 + row, p.N - 1) * p.ldb + c * E;
+        offB = (unsigned)(((long)(min(n0 + row, p.N - 1) - n0) * p.ldb + c * E) * (long)sizeof(T));
     }
+    const T* baseA = A + (long)m0 * p.lda;
+    const T* baseB = B + (long)n0 * p.ldb;
     auto stage = [&](int kt, int st) {
         const unsigned a_dst = lds_base + st * STAGE3, b_dst = a_dst + A3_BYTES;
-        glds16(srcA[0] + (long)kt * KT, a_dst);
-        glds16(srcA[1] + (long)kt * KT, a_dst + 8192);
-        glds16(srcB + (long)kt * KT, b_dst);
+        const T* ka = baseA + (long)kt * KT;
+        const T* kb = baseB + (long)kt * KT;
+        glds16_sv(ka, offA[0], a_dst);
+        glds16_sv(ka, offA[1], a_dst + 8192);
+        glds16_sv(kb, offB, b_dst);
     };
 
+    const int nk = p.K / KT;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
     // the accumulators start at bias + residual: those loads ride behind the first K-stage instead of opening the
     // epilogue (a tile's residual is read before any workgroup writes that tile, so C may alias the residual)
     const float* __restrict__ R = p.residual ? p.residual + bz * p.sR : nullptr;
@@ -381,9 +388,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
 
-    const int nk = p.K / KT;
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
+    retire_vector_loads();   // bias / residual are in the accumulators (and the first two stages have landed)
     for (int kt = 0; kt < nk; ++kt) {
         // this wave's three DMA pieces of tile kt are older than the three of tile kt+1
         if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -475,6 +480,8 @@ template <typename T, typename TC> int launch_duo(const GemmParams& p, hipStream
                "gemm: operand rows must be 16-byte aligned");
     const long tiles = (long)ceil_div(p.M, B2M) * ceil_div(p.N, B2N);
     UW_REQUIRE(tiles * p.batch < (1l << 31), "gemm: too many tiles");
+    UW_REQUIRE((long)B2M * p.lda * (long)sizeof(T) < (1l << 32) && (long)B2N * p.ldb * (long)sizeof(T) < (1l << 32),
+               "gemm: operand row stride too large for 32-bit tile offsets");
     const size_t lds = (size_t)NSTAGE3 * STAGE3;
     static bool attr_set = false;
     if (!attr_set) {
