@@ -41,9 +41,12 @@ __device__ __forceinline__ int pi_row(int i) { return (i & 0x13) | ((i & 4) << 1
 template <typename T> __device__ __forceinline__ uint4 pack_p(const f32x16& p, int s8);
 template <> __device__ __forceinline__ uint4 pack_p<bf16_t>(const f32x16& p, int s8)
 {
-    union { bf16_t h[8]; uint4 u; } pk;
+    // pairs are converted together so that each v_cvt_pk_bf16_f32 fills a whole dword
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    union { bf16x2 h[4]; uint4 u; } pk;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pk.h[k] = (bf16_t)p[s8 + k];
+    for (int k = 0; k < 4; ++k) pk.h[k] = __builtin_convertvector(f32x2{p[s8 + 2 * k], p[s8 + 2 * k + 1]}, bf16x2);
     return pk.u;
 }
 
