@@ -106,16 +106,22 @@ int uw_cost_matrix(const float* rows, int n_sel, const int32_t* n_tok, int B, in
 
 /* dtw.dtw(cost, step_pattern=symmetric1) + boundary extraction (align.py:818-853).  cost f64 [B][n_rows_max][S];
  * n_tok i32 [B]; dir_ws: scratch of uw_dtw_workspace_bytes(); boundaries i32 [B][n_rows_max+1] (n_tok[b]+1 used);
- * optional path_i/path_j i32 [B][n_rows_max+S] and path_len i32 [B]. */
+ * optional path_i/path_j i32 [B][n_rows_max+S] and path_len i32 [B].
+ * A window without a warping path (a NaN or infinite cost leaves cells without a predecessor; the reference returns
+ * no timestamps when dtw raises, align.py:823-827) gets boundaries[b][0] = -1 and path_len[b] < 0; the call itself
+ * still returns 0 because the other windows of the batch are valid. */
 int64_t uw_dtw_workspace_bytes(int B, int n_rows_max, int S);
 int uw_dtw(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, void* dir_ws, int32_t* boundaries,
            int32_t* path_i, int32_t* path_j, int32_t* path_len, void* stream);
 
-/* cost matrix + DTW on the context's rows buffer: boundaries i32 [B][n_text_ctx+1]. n_text i32 [B] device. */
+/* cost matrix + DTW on the context's rows buffer: boundaries i32 [B][n_text_ctx+1]. n_text i32 [B] device.
+ * boundaries[b][0] = -1 marks a window for which no path exists (see uw_dtw). */
 int uw_align(uw_ctx* ctx, const int32_t* n_text, int B, int32_t* boundaries, void* stream);
 
 /* The whole path for a batch of windows: mel -> encoder -> cross K/V -> greedy decode with row capture ->
- * cost matrix -> DTW (core.py:798-1030 numerics).  Same outputs as uw_decode_greedy plus boundaries. */
+ * cost matrix -> DTW (core.py:798-1030 numerics).  Same outputs as uw_decode_greedy plus boundaries.
+ * A context created without alignment heads (the reference's "no alignment" case, align.py:81-84,595-597) skips the
+ * cost matrix and DTW and fills boundaries with -1; boundaries[b][0] = -1 always means "window b has no timestamps". */
 int uw_transcribe_windows(uw_ctx* ctx, const float* audio, int64_t stride, const int32_t* n_samples,
                           const int32_t* prompt_ids, int ld_prompt, const int32_t* prompt_len_host, int B, int max_tokens,
                           int eot, int sot, int ts_begin, int ts_end, int32_t* new_tokens, int32_t* n_new,

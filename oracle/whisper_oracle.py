@@ -176,7 +176,9 @@ class OracleModel:
                 cross.append(w.to(torch.float32).numpy())
                 x = x + self._mlp(self._ln(x, p + ".final_layer_norm"), p)
             x = self._ln(x, "model.decoder.layer_norm")
-            logits = F.linear(x, sd["model.decoder.embed_tokens.weight"]).to(torch.float32).numpy()
+            # the output projection is tied to the token embedding unless the state dict carries its own copy
+            proj = sd.get("proj_out.weight", sd["model.decoder.embed_tokens.weight"])
+            logits = F.linear(x, proj).to(torch.float32).numpy()
         return (logits, cross) if want_attn else logits
 
 

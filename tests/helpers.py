@@ -21,6 +21,21 @@ def synth_audio(seed, n=480000):
     return (0.1 * rng.standard_normal(n) + chirp).astype(np.float32)
 
 
+def bf16_weights(sd):
+    """The weights a bf16 engine computes with, as an fp32 state dict for the oracle: every matrix and conv kernel
+    rounded to bf16 (round-to-nearest-even, as the engine packs them); biases, LayerNorm parameters and position tables
+    stay fp32, and so does the token embedding where it is LOOKED UP -- only its use as the output projection is bf16,
+    hence the separate "proj_out.weight".  An fp32 evaluation on these weights isolates what the bf16 path adds on top
+    of the weight format itself."""
+    import torch
+    out = {}
+    for k, v in sd.items():
+        is_matrix = v.dim() >= 2 and "embed_positions" not in k and "embed_tokens" not in k
+        out[k] = v.to(torch.bfloat16).to(torch.float32) if is_matrix else v
+    out["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"].to(torch.bfloat16).to(torch.float32)
+    return out
+
+
 MICRO_SPECIALS = dict(sot=824, eot=823, ts_begin=924, ts_end=1023)       # vocab 1024
 WHISPER_SPECIALS = dict(sot=50258, eot=50257, ts_begin=50364, ts_end=51864)
 

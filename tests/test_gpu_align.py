@@ -112,3 +112,22 @@ def test_dtw_full_batch_properties_and_c_oracle():
         if b % 16 == 0:
             ci, cj, cb = c_dtw(lib, cost[b, :n])
             assert np.array_equal(ci, i1) and np.array_equal(cj, i2) and np.array_equal(cb, bnd[b, : n + 1])
+
+
+def test_dtw_without_a_path_is_reported_per_window():
+    """A NaN cost row leaves cells without a predecessor: dtw-python raises and the reference returns no timestamps
+    for that chunk (align.py:823-827).  Here the window is marked (boundaries[b][0] = -1, path_len < 0) and the other
+    windows of the batch are unaffected."""
+    rng = np.random.default_rng(3)
+    N, S = 20, 1500
+    cost = -rng.random((3, N, S))
+    bad = cost.copy()
+    bad[1, 7, :] = np.nan
+    n_tok = torch.tensor([N, N, N], dtype=torch.int32)
+    bnd_ok, _, _, len_ok = E.dtw(torch.from_numpy(cost).cuda(), n_tok)
+    bnd, _, _, plen = E.dtw(torch.from_numpy(bad).cuda(), n_tok)
+    bnd, plen, bnd_ok = bnd.cpu().numpy(), plen.cpu().numpy(), bnd_ok.cpu().numpy()
+    assert (len_ok.cpu().numpy() > 0).all()
+    assert plen[1] < 0 and bnd[1, 0] == -1
+    for b in (0, 2):
+        assert plen[b] > 0 and np.array_equal(bnd[b], bnd_ok[b])

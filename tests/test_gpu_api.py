@@ -141,11 +141,14 @@ def test_whisperer_on_gpu_reproduces_reference_core_golden():
     heads = alignment_heads(alignment_heads_key(gold["model"], dims.d_model, "en"), dims.dec_layers, dims.n_heads)
     eng = E.Engine(dims, sd, dtype="f32", max_batch=2, align_heads=heads)
     try:
-        for name in ("plain_two_chunks", "user_prompt", "hyphen_delimiter", "forced_alignment"):
+        for name in CASES:
             kw = dict(CASES[name])
             audio = synth_audio(kw.pop("audio_seed"), kw.pop("n_samples"))
             res = whisperer(model=gold["model"], audio=audio, language="en", tokenizer=WordTokenizer(), engine=eng, **kw)
             ref = gold["cases"][name]
+            if kw.get("stream"):      # generator mode (core.py:238-536): the yielded pieces, in order
+                assert list(res) == ref["pieces"], name
+                continue
             assert [int(t) for t in res["tokens"]] == ref["tokens"], name
             assert res["text"] == ref["text"]
             assert [w["text"] for w in res["words"]] == [w["text"] for w in ref["words"]]
@@ -154,3 +157,30 @@ def test_whisperer_on_gpu_reproduces_reference_core_golden():
             assert all(close), (name, sum(close), len(close))
     finally:
         eng.close()
+
+
+def test_context_without_alignment_heads_transcribes_untimed():
+    """A model key without a mask, or a mask of another size, means "no alignment" in the reference (align.py:81-84,
+    595-597): transcription still works, words come back untimed (core.py:1041-1044), streaming is unaffected."""
+    from whisper_amd.engine import Engine
+    dims = dims_for("micro")
+    sd = synthetic_state_dict(dims, 0, std=0.06)
+    eng = Engine(dims, sd, dtype="f32", max_batch=2)           # align_heads=None
+    ref = _engine(2)
+    try:
+        tok = MicroTokenizer()
+        audio = synth_audio(7)
+        res = whisperer("synthetic:micro", audio, max_tokens=24, tokenizer=tok, engine=eng)
+        timed = whisperer("synthetic:micro", audio, max_tokens=24, tokenizer=tok, engine=ref)
+        assert res["tokens"] == timed["tokens"] and res["text"] == timed["text"] and res["text"]
+        assert res["words"] == []                              # only timed words reach result["words"] (core.py:1051-1052)
+        out = eng.transcribe_windows(torch.from_numpy(audio[None]).cuda(), torch.tensor([480000], dtype=torch.int32),
+                                     [[824, 825, 826, 924]], 24, 823, 824, 924, 1023)
+        assert int(out["boundaries"][0, 0]) == -1
+        pieces = list(whisperer("synthetic:micro", audio, stream=True, max_tokens=16, tokenizer=tok, engine=eng))
+        assert pieces == list(whisperer("synthetic:micro", audio, stream=True, max_tokens=16, tokenizer=tok, engine=ref))
+        al = whisperer("synthetic:micro", audio, transcript="w5 w6 w7", tokenizer=tok, engine=eng)
+        assert al["tokens"] == [5, 6, 7] and al["words"] == []
+    finally:
+        eng.close()
+        ref.close()

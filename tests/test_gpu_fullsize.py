@@ -8,7 +8,7 @@ import torch
 
 from oracle import whisper_oracle as O
 from tests.helpers import WHISPER_SPECIALS as SP
-from tests.helpers import synth_audio
+from tests.helpers import bf16_weights, synth_audio
 from whisper_amd import engine as E
 from whisper_amd.config import alignment_heads, alignment_heads_key, dims_for
 from whisper_amd.weights import synthetic_state_dict
@@ -88,15 +88,23 @@ def test_one_real_size_window_matches_oracle_fp32(small):
         eng.close()
 
 
-@pytest.mark.parametrize("model,B", [("medium", 6), ("large-v3-turbo", 8)])
-def test_largest_shapes_run_and_are_batch_invariant(model, B):
-    """The two largest configurations at their real depth (24 + 24 layers at d = 1024; 32 + 4 layers at d = 1280 with
-    128 mel bins), bf16: duplicated windows agree bit for bit, rows are probability rows, boundaries monotone."""
+EN_ONLY = dict(sot=50257, eot=50256, ts_begin=50363, ts_end=50363 + 1500)      # the .en vocabularies sit one id lower
+
+
+@pytest.mark.parametrize("model,B", [("tiny.en", 1), ("base", 32), ("medium", 15), ("large-v3-turbo", 32)])
+def test_baseline_configs_at_their_size(model, B):
+    """The other benchmark configurations at their real depth and windows per GPU (tiny.en 4 + 4 layers with its 8-head
+    mask and one window; base 6 + 6 at 32; medium 24 + 24 at 15; large-v3-turbo 32 + 4 with 128 mel bins at 32), bf16:
+    duplicated windows agree bit for bit, rows are probability rows, boundaries monotone, and the teacher-forced logits
+    of window 0 (audio -> log-mel -> encoder -> cross K/V -> decoder, all on the GPU) are within 1e-2 of the oracle
+    evaluated in fp32 on the engine's bf16 weights; against the fp32-weight oracle the bound is that figure plus the
+    shift rounding the weights causes in the oracle itself (up to 2e-2 at these depths)."""
     dims = dims_for(model)
+    sp = SP if dims.multilingual else EN_ONLY
     sd = synthetic_state_dict(dims, seed=1)
     heads = alignment_heads(alignment_heads_key(model, dims.d_model, "en"), dims.dec_layers, dims.n_heads)
+    assert heads, model
     eng = E.Engine(dims, sd, dtype="bf16", max_batch=B, align_heads=heads)
-    del sd
     try:
         base = [synth_audio(60), synth_audio(61, 300000)]
         order = [i % 2 for i in range(B)]
@@ -104,21 +112,36 @@ def test_largest_shapes_run_and_are_batch_invariant(model, B):
         for b, i in enumerate(order):
             buf[b, : len(base[i])] = base[i]
         n_samples = torch.tensor([len(base[i]) for i in order], dtype=torch.int32)
-        prompt = [SP["sot"], 50259, 50359, SP["ts_begin"]]
-        res = eng.transcribe_windows(torch.from_numpy(buf).to(DEV), n_samples, [prompt] * B, len(prompt) + 10, SP["eot"], SP["sot"],
-                                     SP["ts_begin"], SP["ts_end"])
+        prompt = [sp["sot"], sp["sot"] + 1, sp["sot"] + 101, sp["ts_begin"]] if dims.multilingual else [sp["sot"], sp["sot"] + 101, sp["ts_begin"], 2425]
+        n_gen = 10
+        res = eng.transcribe_windows(torch.from_numpy(buf).to(DEV), n_samples, [prompt] * B, len(prompt) + n_gen, sp["eot"], sp["sot"],
+                                     sp["ts_begin"], sp["ts_end"])
         n_text = res["n_text"].cpu().numpy()
-        assert (res["n_new"].cpu().numpy() == 10).all()
+        assert (res["n_new"].cpu().numpy() == n_gen).all()
         toks, bnd = res["new_tokens"].cpu().numpy(), res["boundaries"].cpu().numpy()
         rows = eng.attn_rows(B, int(max(1, n_text.max()))).cpu().numpy()
         for b in range(2, B):
             assert np.array_equal(toks[b], toks[b % 2]) and np.array_equal(bnd[b], bnd[b % 2])
             assert np.array_equal(rows[b, :, : n_text[b]], rows[b % 2, :, : n_text[b]])
-        for b in range(2):
+        for b in range(min(2, B)):
             nt = int(n_text[b])
             if nt:
                 assert np.allclose(rows[b, :, :nt].sum(-1), 1.0, atol=2e-3)
                 bd = bnd[b, : nt + 1]
                 assert bd[0] == 0 and np.all(np.diff(bd) >= 0) and bd[-1] <= 1500
+        # teacher-forced on the GPU's own token stream, cross K/V of the batch still in the context
+        seq = prompt + toks[0, :n_gen].tolist()
+        got = eng.decoder_forward(torch.tensor([seq] * B, dtype=torch.int32), logits_all=True, logits_last=False)["logits_all"][0].cpu().numpy()
+        mel_ref = O.log_mel_segment(base[0], dims.n_mels)
+        om = O.OracleModel(sd, dims.n_heads)
+        ref32 = om.decode_full(seq, om.encode(mel_ref))[0]
+        del om
+        om_r = O.OracleModel(bf16_weights(sd), dims.n_heads)
+        ref = om_r.decode_full(seq, om_r.encode(mel_ref))[0]
+        err, err32, floor = np.abs(got - ref).max(), np.abs(got - ref32).max(), np.abs(ref - ref32).max()
+        print(f"{model} B={B} bf16 max|dlogit|: {err:.2e} vs the fp32 oracle on the engine's bf16 weights, {err32:.2e} vs fp32 weights "
+              f"(weight rounding alone: {floor:.2e})")
+        assert err <= 1e-2, (model, err)      # bf16 contract figure
+        assert err32 <= floor + 1e-2, (model, err32, floor)
     finally:
         eng.close()

@@ -228,7 +228,8 @@ def _align_transcript(run: _Run, audio: np.ndarray, transcript: str) -> Dict:
     for i0 in range(0, len(windows), eng.max_batch):
         group = windows[i0:i0 + eng.max_batch]
         texts = [[t for t in tokens[w[2]:w[3]] if run.is_text(t)] for w in group]
-        live = [k for k, t in enumerate(texts) if t and len(prompt) + len(t) - 1 <= eng.n_text_ctx]
+        # no alignment heads (unknown model key / mask of another size): every window comes back empty (align.py:595-597)
+        live = [k for k, t in enumerate(texts) if t and eng.heads and len(prompt) + len(t) - 1 <= eng.n_text_ctx]
         group_words: List[List[Dict]] = [[] for _ in group]
         if live:
             stride = max(group[k][1] - group[k][0] for k in live)
@@ -243,7 +244,8 @@ def _align_transcript(run: _Run, audio: np.ndarray, transcript: str) -> Dict:
             eng.attn_rows_forced([prompt] * len(live), [texts[k] for k in live])
             bnd = eng.align(torch.tensor([len(texts[k]) for k in live], dtype=torch.int32)).cpu().numpy()
             for r, k in enumerate(live):
-                group_words[k] = run.words_for(texts[k], bnd[r, :len(texts[k]) + 1].tolist(), group[k][0], 0.0)
+                if bnd[r, 0] >= 0:     # -1: DTW found no path for this window (align.py:823-827)
+                    group_words[k] = run.words_for(texts[k], bnd[r, :len(texts[k]) + 1].tolist(), group[k][0], 0.0)
         results += group_words
     words = A.merge_overlapping_alignment_results(results, windows)
     return {"text": transcript, "words": words, "tokens": tokens, "language": run.language}
@@ -292,7 +294,9 @@ def _transcribe(run: _Run, audio: np.ndarray, delimiter, diarization, big_model)
         raw = run.tok.decode(text).strip() if text else ""
         if raw:
             texts.append(raw)
-        words = run.words_for(text, bnd, start, context_dur) if (text and run.eng.heads and run.include_timestamps) else []
+        # boundaries starting with -1: no alignment heads in the context, or DTW found no path (align.py:595-597,823-827)
+        aligned = bool(text) and bool(run.eng.heads) and run.include_timestamps and len(bnd) > 0 and bnd[0] >= 0
+        words = run.words_for(text, bnd, start, context_dur) if aligned else []
         if not words and raw:
             words = [{"text": w, "start": None, "end": None} for w in raw.split()]
         all_words.extend(w for w in words if w.get("start") is not None)

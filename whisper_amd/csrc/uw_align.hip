@@ -209,6 +209,9 @@ __global__ __launch_bounds__(64 * DTW_MAX_BANDS) void dtw_kernel(const double* _
             }
         }
         if (s_len[1]) len = -2;
+        // no warping path (a NaN / Inf cost leaves cells without a predecessor) or a stalled band: the window gets no
+        // boundaries at all, as the reference returns no timestamps when dtw raises (align.py:823-827)
+        if (len < 0) bnd[0] = -1;
         s_len[0] = len;
         if (path_len) path_len[b] = len;
     }
@@ -250,11 +253,9 @@ int uw_dtw_run(const double* cost, const int32_t* n_tok, int B, int n_rows_max, 
     const int dir_words = (int)uw_dtw_dir_words(S);
     const size_t lds = (size_t)(DTW_MAX_BANDS - 1) * S * 8 + (DTW_MAX_BANDS + 4) * 4 + (size_t)2 * (n_rows_max + S) * 2 + 16;
     UW_REQUIRE(lds <= 160 * 1024, "dtw: S=%d needs %zu bytes of LDS", S, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceFlag attr_set;
+    if (attr_set.first_use())
         UW_HIP_CHECK(hipFuncSetAttribute((const void*)dtw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(dtw_kernel, dim3(B), dim3(64 * DTW_MAX_BANDS), lds, s, cost, n_tok, n_rows_max, S,
                        (uint32_t*)dir_ws, dir_words, boundaries, path_i, path_j, path_len);
     UW_LAUNCH_CHECK();

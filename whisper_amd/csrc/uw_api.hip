@@ -260,8 +260,8 @@ int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
         RUN(load_mlp(c, cur, l));
     }
     // the KV-cached step reads its weights as whole MFMA operand blocks: second, fragment-major copy.  The three
-    // products that follow a LayerNorm (q|k|v, cross q, fc1) get the LayerNorm folded in: scale into the weights,
-    // shift into the bias, plus the row sums the kernel needs for the mean.
+    // products that follow a LayerNorm (q|k|v, cross q, fc1) run with the LayerNorm fused in: its shift goes into
+    // the bias, its scale is applied to the operand in the kernel, and the kernel needs gamma-weighted row sums.
     {
         const long f = 4 * d;
         void* tmp = nullptr;   // row-major staging for the folded weights; owned by the context like every other buffer
@@ -341,12 +341,14 @@ int alloc_workspace(uw_ctx* c)
     ALLOC(c->cross_vt, Ld * Bm * d * Spad * es, true);
     ALLOC(c->self_kv, Ld * Bm * Tm * 2 * d * es, true);
     ALLOC(c->d_x, Bm * Tm * d * 4, true);
-    ALLOC(c->d_ln, Bm * Tm * d * es, true);
+    // LayerNorm output, attention output and MLP hidden state are carried as [hi | lo] bf16 pairs where logits are
+    // produced (see GemmParams), hence twice the width
+    ALLOC(c->d_ln, Bm * Tm * 2 * d * es, true);
     ALLOC(c->d_qkv, Bm * Tm * 3 * d * es, true);
     ALLOC(c->d_vt, Bm * d * Tm * es, true);
-    ALLOC(c->d_attn, Bm * Tm * d * es, true);
-    ALLOC(c->d_mlp, Bm * Tm * 4 * d * es, true);
-    ALLOC(c->d_last, Bm * d * 4, true);
+    ALLOC(c->d_attn, Bm * Tm * 2 * d * es, true);
+    ALLOC(c->d_mlp, Bm * Tm * 8 * d * es, true);
+    ALLOC(c->d_last, ((Bm + 15) & ~15l) * d * 4, true);
     ALLOC(c->split_ws, Bm * (d / 64) * 16 * 66 * 4, true);
     c->logits_ld = (c->V + 3) & ~3;
     ALLOC(c->logits, Bm * c->logits_ld * 4, true);
@@ -368,10 +370,12 @@ int alloc_workspace(uw_ctx* c)
 // ---- launch sequences -------------------------------------------------------------------------------------
 int gemm(uw_ctx* c, const void* A, long lda, const void* Bw, long ldb, void* C, long ldc, bool out_f32, int M, int N,
          int K, const float* bias, int act, const float* residual, long ldr, hipStream_t s, int batch = 1, long sA = 0,
-         long sB = 0, long sC = 0, long sR = 0, int bias_mode = 1, long c_group = 0)
+         long sB = 0, long sC = 0, long sR = 0, int bias_mode = 1, long c_group = 0, int kwrap_a = 0, int kwrap_b = 0,
+         int c_split = 0)
 {
     GemmParams p;
     p.c_group = c_group;
+    p.kwrap_a = kwrap_a; p.kwrap_b = kwrap_b; p.c_split = c_split;
     p.A = A; p.B = Bw; p.C = C; p.bias = bias; p.residual = residual;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
     p.sA = sA; p.sB = sB; p.sC = sC; p.sR = sR;
@@ -379,16 +383,16 @@ int gemm(uw_ctx* c, const void* A, long lda, const void* Bw, long ldb, void* C, 
     p.bias_mode = bias ? bias_mode : 0;
     p.act = act;
     // decode-step shapes: few rows, modest N -> stream the weights once over many small workgroups
-    if (batch == 1 && M <= 128 && N <= 8192 && !c_group) return uw_gemm_skinny(c->dt, out_f32 ? 1 : 0, p, s);
+    if (batch == 1 && M <= 128 && N <= 8192 && !c_group && !kwrap_a && !kwrap_b && !c_split) return uw_gemm_skinny(c->dt, out_f32 ? 1 : 0, p, s);
     return uw_gemm(c->dt, out_f32 ? 1 : 0, p, s);
 }
 
 // decode-step product: A [M][K] and W [N][K] fragment-major, C row-major (or fragment-major when c_packed)
-int gemm_step(uw_ctx* c, const void* A, const void* Wp, void* C, long ldc, bool out_f32, int M, int N, int K, const float* bias,
-              int act, const float* residual, long ldr, bool c_packed, hipStream_t s)
+int gemm_step(uw_ctx* c, const void* A, const void* A_lo, const void* Wp, void* C, long ldc, bool out_f32, int M, int N, int K,
+              const float* bias, int act, const float* residual, long ldr, bool c_packed, hipStream_t s)
 {
     GemmParams p;
-    p.A = A; p.B = Wp; p.C = C; p.bias = bias; p.residual = residual;
+    p.A = A; p.A_lo = A_lo; p.B = Wp; p.C = C; p.bias = bias; p.residual = residual;
     p.ldc = ldc; p.ldr = ldr; p.M = M; p.N = N; p.K = K;
     p.bias_mode = bias ? 1 : 0;
     p.act = act;
@@ -398,15 +402,26 @@ int gemm_step(uw_ctx* c, const void* A, const void* Wp, void* C, long ldc, bool 
 }
 
 // decode-step product with the preceding LayerNorm folded in: A is the residual stream x (x layout)
-int gemm_step_ln(uw_ctx* c, const float* x, const void* Wp, const float* bias_ln, const float* wsum, void* C, long ldc, int M, int N,
-                 int K, int act, bool c_packed, hipStream_t s)
+int gemm_step_ln(uw_ctx* c, const float* x, const void* Wp, const float* gamma, const float* bias_ln, const float* wsum, void* C, long ldc,
+                 int M, int N, int K, int act, bool c_packed, hipStream_t s, void* C_lo = nullptr, bool out_f32 = false)
 {
     GemmParams p;
-    p.A = x; p.B = Wp; p.C = C; p.bias = bias_ln; p.wsum = wsum;
+    p.A = x; p.B = Wp; p.C = C; p.C_lo = C_lo; p.bias = bias_ln; p.wsum = wsum; p.gamma = gamma;
     p.ldc = ldc; p.M = M; p.N = N; p.K = K;
     p.bias_mode = 1; p.act = act;
     p.ab_packed = 1; p.c_packed = c_packed ? 1 : 0; p.ln_fused = 1;
-    return uw_gemm_skinny(c->dt, 0, p, s);
+    return uw_gemm_skinny(c->dt, out_f32 ? 1 : 0, p, s);
+}
+
+// logits[m][:] = LayerNorm(x[m]) . tok_emb^T for M rows of the residual stream held in the step's x layout.  For bf16
+// compute the normalised row is written as a [hi | lo] pair and the product runs over 2 d with the embedding
+// repeating (GemmParams::kwrap_b), so the logits see no bf16-rounded activations; `ln` is scratch for [M][2 d].
+int logits_from_x(uw_ctx* c, const float* x, int M, void* ln, float* logits, hipStream_t s)
+{
+    const int d = c->d, split = c->dt == UW_BF16 ? 1 : 0, w = split ? 2 : 1;
+    RUN(uw_layernorm(c->dt, x, ln, nullptr, c->dec_ln_g, c->dec_ln_b, M, d, s, 0, 1, split));
+    return gemm(c, ln, w * d, c->tok_emb, d, logits, c->logits_ld, true, M, c->V, w * d, nullptr, 0, nullptr, 0, s, 1, 0, 0, 0, 0, 1, 0, 0,
+                split ? d : 0);
 }
 
 int encoder_forward(uw_ctx* c, const float* mel, int B, hipStream_t s)
@@ -461,6 +476,8 @@ int cross_kv_project(uw_ctx* c, int B, hipStream_t s)
     return UW_OK;
 }
 
+// row idx[b] of window b -> row b of `out`, in the decode step's x layout (the operand of the logits product)
+template <typename TT>
 __global__ void gather_last_rows_kernel(const float* __restrict__ x, float* __restrict__ out, const int32_t* __restrict__ idx,
                                         int fixed_idx, int T, int d)
 {
@@ -468,14 +485,17 @@ __global__ void gather_last_rows_kernel(const float* __restrict__ x, float* __re
     int t = idx ? idx[b] : fixed_idx;
     t = min(max(t, 0), T - 1);
     const f32x4* src = (const f32x4*)(x + ((long)b * T + t) * d);
-    f32x4* dst = (f32x4*)(out + (long)b * d);
-    for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) *(f32x4*)(out + x_elem_offset<TT>(b, i * 4, d)) = src[i];
 }
 
 // Multi-token decoder pass over ids [B][T] (positions 0..T-1); fills the self K/V cache for those positions.
 //   rows_first/rows_count (device, per window) select query rows whose alignment-head probabilities go to c->rows
 //   all_probs: [Ld][B][H][T][S] or null;  logits_all: [B][T][V] or null;  last_idx: device per-window index of the row
 //   whose logits go to c->logits (or fixed_last when null and want_last)
+// A pass that produces logits carries the operands of its products as [hi | lo] bf16 pairs (bf16 compute only, see
+// GemmParams): LayerNorm outputs, attention outputs and the MLP hidden state then keep ~16 mantissa bits, so the
+// logits differ from an fp32 evaluation on the same bf16 weights by the rounding of q, k, v and the probabilities
+// alone.  A pass that only emits attention rows (forced alignment, the greedy loop's row fix-up) runs without it.
 int decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, const int32_t* rows_first,
                     const int32_t* rows_count, float* all_probs, float* logits_all, bool want_last, const int32_t* last_idx,
                     int fixed_last, hipStream_t s)
@@ -485,6 +505,10 @@ int decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, con
     UW_REQUIRE(T > 0 && T <= Tm, "decoder: T=%d outside 1..%d", T, Tm);
     const long M = (long)B * T;
     const int Tpad = (T + 63) & ~63;
+    const bool split = c->dt == UW_BF16 && (logits_all || want_last);
+    const int w = split ? 2 : 1;            // operand rows are w * K elements wide
+    const int kw = split ? d : 0;           // ... and the weights repeat after K
+    const int kw4 = split ? 4 * d : 0;
     RUN(uw_embed_tokens(c->d_x, c->tok_emb32, c->dec_pos, ids, ld_ids, nullptr, B, T, d, c->V, Tm, s));
     for (size_t li = 0; li < c->dec.size(); ++li) {
         auto& l = c->dec[li];
@@ -492,22 +516,22 @@ int decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, con
         void* ckv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c);
         void* cvt = (char*)c->cross_vt + li * cross_vt_layer_bytes(c);
         // --- causal self-attention ---
-        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.self.ln_g, l.self.ln_b, M, d, s));
-        RUN(gemm(c, c->d_ln, d, l.self.wq, d, c->d_qkv, d, false, (int)M, d, d, l.self.bq, 0, nullptr, 0, s));
-        RUN(gemm(c, c->d_ln, d, l.self.wkv, d, skv, 64, false, T, 2 * d, d, l.self.bkv, 0, nullptr, 0, s, B, (long)T * d, 0,
-                 (long)Tm * 2 * d, 0, 1, (long)Tm * 64));
-        RUN(gemm(c, l.self.wv, d, c->d_ln, d, c->d_vt, Tpad, false, d, T, d, l.self.bv, 0, nullptr, 0, s, B, 0, (long)T * d,
-                 (long)d * Tpad, 0, 2));
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.self.ln_g, l.self.ln_b, M, d, s, 0, 0, split));
+        RUN(gemm(c, c->d_ln, w * d, l.self.wq, d, c->d_qkv, d, false, (int)M, d, w * d, l.self.bq, 0, nullptr, 0, s, 1, 0, 0, 0, 0, 1, 0, 0, kw));
+        RUN(gemm(c, c->d_ln, w * d, l.self.wkv, d, skv, 64, false, T, 2 * d, w * d, l.self.bkv, 0, nullptr, 0, s, B, (long)T * w * d, 0,
+                 (long)Tm * 2 * d, 0, 1, (long)Tm * 64, 0, kw));
+        RUN(gemm(c, l.self.wv, d, c->d_ln, w * d, c->d_vt, Tpad, false, d, T, w * d, l.self.bv, 0, nullptr, 0, s, B, 0, (long)T * w * d,
+                 (long)d * Tpad, 0, 2, 0, kw, 0));
         AttnParams a;
         a.Q = c->d_qkv; a.K = skv; a.VT = c->d_vt; a.O = c->d_attn;
-        a.ldq = d; a.ldk = 64; a.sKh = (long)Tm * 64; a.ldvt = Tpad; a.ldo = d;
-        a.sQ = (long)T * d; a.sK = (long)Tm * 2 * d; a.sVT = (long)d * Tpad; a.sO = (long)T * d;
+        a.ldq = d; a.ldk = 64; a.sKh = (long)Tm * 64; a.ldvt = Tpad; a.ldo = w * d; a.o_split = split;
+        a.sQ = (long)T * d; a.sK = (long)Tm * 2 * d; a.sVT = (long)d * Tpad; a.sO = (long)T * w * d;
         a.B = B; a.H = H; a.Sq = T; a.Sk = T; a.causal = 1;
         RUN(uw_flash_attention(c->dt, a, s));
-        RUN(gemm(c, c->d_attn, d, l.self.wo, d, c->d_x, d, true, (int)M, d, d, l.self.bo, 0, c->d_x, d, s));
+        RUN(gemm(c, c->d_attn, w * d, l.self.wo, d, c->d_x, d, true, (int)M, d, w * d, l.self.bo, 0, c->d_x, d, s, 1, 0, 0, 0, 0, 1, 0, 0, kw));
         // --- cross-attention over the encoder frames ---
-        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.cross.ln_g, l.cross.ln_b, M, d, s));
-        RUN(gemm(c, c->d_ln, d, l.cross.wq, d, c->d_qkv, d, false, (int)M, d, d, l.cross.bq, 0, nullptr, 0, s));
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.cross.ln_g, l.cross.ln_b, M, d, s, 0, 0, split));
+        RUN(gemm(c, c->d_ln, w * d, l.cross.wq, d, c->d_qkv, d, false, (int)M, d, w * d, l.cross.bq, 0, nullptr, 0, s, 1, 0, 0, 0, 0, 1, 0, 0, kw));
         ProbParams pp;
         pp.Q = c->d_qkv; pp.K = ckv; pp.ldq = d; pp.ldk = 64; pp.sKh = (long)S * 64; pp.sQ = (long)T * d; pp.sK = (long)S * 2 * d;
         pp.B = B; pp.Sq = T; pp.Sk = S;
@@ -533,25 +557,25 @@ int decoder_forward(uw_ctx* c, const int32_t* ids, int ld_ids, int B, int T, con
             }
         }
         a.Q = c->d_qkv; a.K = ckv; a.VT = cvt; a.O = c->d_attn;
-        a.ldq = d; a.ldk = 64; a.sKh = (long)S * 64; a.ldvt = c->Spad; a.ldo = d;
-        a.sQ = (long)T * d; a.sK = (long)S * 2 * d; a.sVT = (long)d * c->Spad; a.sO = (long)T * d;
+        a.ldq = d; a.ldk = 64; a.sKh = (long)S * 64; a.ldvt = c->Spad; a.ldo = w * d;
+        a.sQ = (long)T * d; a.sK = (long)S * 2 * d; a.sVT = (long)d * c->Spad; a.sO = (long)T * w * d;
         a.Sq = T; a.Sk = S; a.causal = 0;
         RUN(uw_flash_attention(c->dt, a, s));
-        RUN(gemm(c, c->d_attn, d, l.cross.wo, d, c->d_x, d, true, (int)M, d, d, l.cross.bo, 0, c->d_x, d, s));
+        RUN(gemm(c, c->d_attn, w * d, l.cross.wo, d, c->d_x, d, true, (int)M, d, w * d, l.cross.bo, 0, c->d_x, d, s, 1, 0, 0, 0, 0, 1, 0, 0, kw));
         // --- MLP ---
-        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.ln2_g, l.ln2_b, M, d, s));
-        RUN(gemm(c, c->d_ln, d, l.w1, d, c->d_mlp, 4 * d, false, (int)M, 4 * d, d, l.b1, 1, nullptr, 0, s));
-        RUN(gemm(c, c->d_mlp, 4 * d, l.w2, 4 * d, c->d_x, d, true, (int)M, d, 4 * d, l.b2, 0, c->d_x, d, s));
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, l.ln2_g, l.ln2_b, M, d, s, 0, 0, split));
+        RUN(gemm(c, c->d_ln, w * d, l.w1, d, c->d_mlp, w * 4 * d, false, (int)M, 4 * d, w * d, l.b1, 1, nullptr, 0, s, 1, 0, 0, 0, 0, 1, 0, 0, kw, split));
+        RUN(gemm(c, c->d_mlp, w * 4 * d, l.w2, 4 * d, c->d_x, d, true, (int)M, d, w * 4 * d, l.b2, 0, c->d_x, d, s, 1, 0, 0, 0, 0, 1, 0, 0, kw4));
     }
     if (logits_all) {
-        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, c->dec_ln_g, c->dec_ln_b, M, d, s));
-        RUN(gemm(c, c->d_ln, d, c->tok_emb, d, logits_all, c->V, true, (int)M, c->V, d, nullptr, 0, nullptr, 0, s));
+        RUN(uw_layernorm(c->dt, c->d_x, c->d_ln, nullptr, c->dec_ln_g, c->dec_ln_b, M, d, s, 0, 0, split));
+        RUN(gemm(c, c->d_ln, w * d, c->tok_emb, d, logits_all, c->V, true, (int)M, c->V, w * d, nullptr, 0, nullptr, 0, s, 1, 0, 0, 0, 0, 1, 0, 0, kw));
     }
     if (want_last) {
-        hipLaunchKernelGGL(gather_last_rows_kernel, dim3(B), dim3(256), 0, s, c->d_x, c->d_last, last_idx, fixed_last, T, d);
+        if (c->dt == UW_F32) hipLaunchKernelGGL(gather_last_rows_kernel<float>, dim3(B), dim3(256), 0, s, c->d_x, c->d_last, last_idx, fixed_last, T, d);
+        else hipLaunchKernelGGL(gather_last_rows_kernel<bf16_t>, dim3(B), dim3(256), 0, s, c->d_x, c->d_last, last_idx, fixed_last, T, d);
         UW_LAUNCH_CHECK();
-        RUN(uw_layernorm(c->dt, c->d_last, c->d_ln, nullptr, c->dec_ln_g, c->dec_ln_b, B, d, s));
-        RUN(gemm(c, c->d_ln, d, c->tok_emb, d, c->logits, c->logits_ld, true, B, c->V, d, nullptr, 0, nullptr, 0, s));
+        RUN(logits_from_x(c, c->d_last, B, c->d_ln, c->logits, s));
     }
     return UW_OK;
 }
@@ -585,10 +609,13 @@ int decoder_step_chunk(uw_ctx* c, int b0, int B, hipStream_t s)
     const int d = c->d, S = c->S, H = c->H, Tm = c->Tm;
     const size_t es = c->es;
     float* x = c->d_x + (long)b0 * d;
-    char* ln = (char*)c->d_ln + (size_t)b0 * d * es;
     char* qkv = (char*)c->d_qkv + (size_t)b0 * 3 * d * es;
     char* att = (char*)c->d_attn + (size_t)b0 * d * es;
     char* mlp = (char*)c->d_mlp + (size_t)b0 * 4 * d * es;
+    // bf16 compute: attention outputs and the MLP hidden state go to the next product as hi + lo planes (GemmParams)
+    const size_t plane = (size_t)((c->Bm + 15) & ~15);
+    char* att_lo = c->dt == UW_BF16 ? att + plane * d * es : nullptr;
+    char* mlp_lo = c->dt == UW_BF16 ? mlp + plane * 4 * d * es : nullptr;
     float* logits = c->logits + (long)b0 * c->logits_ld;
     const int32_t* pos = c->st_pos + b0;
     const int32_t* active = c->st_active + b0;
@@ -601,15 +628,15 @@ int decoder_step_chunk(uw_ctx* c, int b0, int B, hipStream_t s)
         auto& l = c->dec[li];
         char* skv = (char*)c->self_kv + li * self_kv_layer_bytes(c) + (size_t)b0 * Tm * 2 * d * es;
         char* ckv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c) + (size_t)b0 * S * 2 * d * es;
-        RUN(gemm_step_ln(c, x, l.self.wqkv_p, l.self.bln, l.self.wsum, qkv, 3 * d, B, 3 * d, d, 0, false, s));
+        RUN(gemm_step_ln(c, x, l.self.wqkv_p, l.self.ln_g, l.self.bln, l.self.wsum, qkv, 3 * d, B, 3 * d, d, 0, false, s));
         SelfDecodeParams sp;
-        sp.qkv = qkv; sp.kcache = skv; sp.vcache = skv + (size_t)Tm * d * es; sp.out = att;
+        sp.qkv = qkv; sp.kcache = skv; sp.vcache = skv + (size_t)Tm * d * es; sp.out = att; sp.out_lo = att_lo;
         sp.pos = pos; sp.active = active; sp.ld_cache = 64; sp.cache_sB = (long)Tm * 2 * d; sp.cache_sH = (long)Tm * 64; sp.out_packed = 1; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
         RUN(uw_self_attn_decode(c->dt, sp, s));
-        RUN(gemm_step(c, att, l.self.wo_p, x, d, true, B, d, d, l.self.bo, 0, x, d, false, s));
-        RUN(gemm_step_ln(c, x, l.cross.wq_p, l.cross.bln, l.cross.wsum, qkv, d, B, d, d, 0, false, s));
+        RUN(gemm_step(c, att, att_lo, l.self.wo_p, x, d, true, B, d, d, l.self.bo, 0, x, d, false, s));
+        RUN(gemm_step_ln(c, x, l.cross.wq_p, l.cross.ln_g, l.cross.bln, l.cross.wsum, qkv, d, B, d, d, 0, false, s));
         CrossDecodeParams cp;
-        cp.q = qkv; cp.K = ckv; cp.V = ckv + (size_t)S * d * es; cp.out = att;
+        cp.q = qkv; cp.K = ckv; cp.V = ckv + (size_t)S * d * es; cp.out = att; cp.out_lo = att_lo;
         cp.rows_sB = (long)c->n_sel * Tm * S; cp.rows_sSel = (long)Tm * S;
         cp.rows = c->rows ? c->rows + (long)b0 * cp.rows_sB : nullptr;
         cp.row_index = c->st_n_text + b0; cp.active = active;
@@ -626,13 +653,11 @@ int decoder_step_chunk(uw_ctx* c, int b0, int B, hipStream_t s)
         RUN(uw_cross_attn_decode(c->dt, cp, s));
         if (timed) { UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used + 1], s)); c->prof_used += 2; }
         if (c->prof_on) { ++c->prof_launches; c->prof_windows += B; }
-        RUN(gemm_step(c, att, l.cross.wo_p, x, d, true, B, d, d, l.cross.bo, 0, x, d, false, s));
-        RUN(gemm_step_ln(c, x, l.w1_p, l.b1ln, l.w1sum, mlp, 4 * d, B, 4 * d, d, 1, true, s));
-        RUN(gemm_step(c, mlp, l.w2_p, x, d, true, B, d, 4 * d, l.b2, 0, x, d, false, s));
+        RUN(gemm_step(c, att, att_lo, l.cross.wo_p, x, d, true, B, d, d, l.cross.bo, 0, x, d, false, s));
+        RUN(gemm_step_ln(c, x, l.w1_p, l.ln2_g, l.b1ln, l.w1sum, mlp, 4 * d, B, 4 * d, d, 1, true, s, mlp_lo));
+        RUN(gemm_step(c, mlp, mlp_lo, l.w2_p, x, d, true, B, d, 4 * d, l.b2, 0, x, d, false, s));
     }
-    RUN(uw_layernorm(c->dt, x, ln, nullptr, c->dec_ln_g, c->dec_ln_b, B, d, s, 0, 1));
-    RUN(gemm(c, ln, d, c->tok_emb, d, logits, c->logits_ld, true, B, c->V, d, nullptr, 0, nullptr, 0, s));
-    return UW_OK;
+    return logits_from_x(c, x, B, (char*)c->d_ln + (size_t)b0 * 2 * d * es, logits, s);
 }
 
 __global__ void greedy_init_kernel(GreedyState st, const int32_t* __restrict__ prompt, int ld_prompt,
@@ -698,12 +723,6 @@ __global__ void count_active_kernel(const int32_t* __restrict__ active, int n, i
     for (int i = threadIdx.x; i < n; i += 64) c += active[i] ? 1 : 0;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if (threadIdx.x == 0) *out = c;
-}
-
-__global__ void prompt_rows_kernel(const int32_t* __restrict__ plen, int32_t* __restrict__ q_first, int32_t* __restrict__ q_count, int B)
-{
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < B) { q_first[b] = plen[b] - 1; q_count[b] = 1; }
 }
 
 GreedyState state_of(uw_ctx* c)
@@ -923,10 +942,10 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
     UW_LAUNCH_CHECK();
     const int max_steps = std::max(0, std::min(max_tokens, c->Tm) - Pmin);
     if (max_steps > 0) {
-        // prompt pass: fills the self K/V cache, captures attention row 0, gives the logits of the last prompt position
-        hipLaunchKernelGGL(prompt_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, s, plen_dev, c->st_qfirst, c->st_qcount, B);
-        UW_LAUNCH_CHECK();
-        RUN(decoder_forward(c, c->st_tokens, c->Tm, B, Pmax, c->st_qfirst, c->st_qcount, nullptr, nullptr, true, c->st_pos, 0, s));
+        // prompt pass over every prompt token but the last: fills the self K/V cache.  The last prompt token then goes
+        // through the KV-cached step like every generated one, so all logits and all captured attention rows come from
+        // one set of kernels (positions a shorter prompt does not have are overwritten by that window's own steps).
+        if (Pmax > 1) RUN(decoder_forward(c, c->st_tokens, c->Tm, B, Pmax - 1, nullptr, nullptr, nullptr, nullptr, false, nullptr, 0, s));
         // split the windows into up to four ranges, one stream each
         const int n_sub = c->n_streams <= 1 ? 1 : (B >= 64 ? std::min(4, c->n_streams) : (B >= 32 ? 2 : 1));
         int sub_b0[5];
@@ -956,7 +975,7 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
                 sk.tokens += (long)b0 * st.ld_tok; sk.text_ids += (long)b0 * st.ld_tok;
                 sk.pos += b0; sk.n_new += b0; sk.n_text += b0; sk.active += b0; sk.dirty_from += b0; sk.max_new += b0;
                 sk.n_active = c->st_n_active + k;
-                if (step > 0) RUN(decoder_step(c, b0, Bn, ss[k]));
+                RUN(decoder_step(c, b0, Bn, ss[k]));
                 RUN(uw_argmax_rows(c->logits + (long)b0 * c->logits_ld, c->logits_ld, Bn, c->V, c->st_next + b0, ss[k]));
                 RUN(uw_greedy_advance(sk, c->st_next + b0, Bn, eot, sot, ts_begin, ts_end, ss[k]));
                 if ((step & 7) == 7 && step + 1 < max_steps) {
@@ -1060,7 +1079,8 @@ int uw_transcribe_windows(uw_ctx* c, const float* audio, int64_t stride, const i
                           int32_t* boundaries, void* stream)
 {
     RUN(check_batch(c, B));
-    UW_REQUIRE(audio && n_samples && n_text && boundaries, "uw_transcribe_windows: null argument");
+    UW_REQUIRE(audio && n_samples && n_text, "uw_transcribe_windows: null argument");
+    UW_REQUIRE(boundaries || c->n_sel == 0, "uw_transcribe_windows: boundaries missing");
     hipStream_t s = (hipStream_t)stream;
     // the log-mel tile is parked in the (not yet used) decoder MLP scratch
     float* mel = (float*)c->e_mlp;
@@ -1069,6 +1089,12 @@ int uw_transcribe_windows(uw_ctx* c, const float* audio, int64_t stride, const i
     RUN(cross_kv_project(c, B, s));
     RUN(uw_decode_greedy(c, prompt_ids, ld_prompt, prompt_len_host, B, max_tokens, eot, sot, ts_begin, ts_end, new_tokens, n_new,
                          text_ids, n_text, stream));
+    if (c->n_sel == 0) {
+        // a context without alignment heads (unknown model key or a mask of the wrong size, align.py:81-84,595-597)
+        // transcribes without timestamps: boundary row b starts with -1, "no alignment for this window"
+        if (boundaries) UW_HIP_CHECK(hipMemsetAsync(boundaries, 0xff, (size_t)B * (c->Tm + 1) * 4, s));
+        return UW_OK;
+    }
     return uw_align(c, n_text, B, boundaries, stream);
 }
 

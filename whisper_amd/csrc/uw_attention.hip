@@ -253,6 +253,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         union { bf16_t h[4]; uint2 u; } pk;
                         pk.h[0] = (bf16_t)v0; pk.h[1] = (bf16_t)v1; pk.h[2] = (bf16_t)v2; pk.h[3] = (bf16_t)v3;
                         *(uint2*)((bf16_t*)orow + hd) = pk.u;
+                        if (p.o_split) {   // split activations: lo half of the row, H * 64 columns further
+                            union { bf16_t h[4]; uint2 u; } lo;
+                            lo.h[0] = (bf16_t)(v0 - (float)pk.h[0]); lo.h[1] = (bf16_t)(v1 - (float)pk.h[1]);
+                            lo.h[2] = (bf16_t)(v2 - (float)pk.h[2]); lo.h[3] = (bf16_t)(v3 - (float)pk.h[3]);
+                            *(uint2*)((bf16_t*)orow + p.H * 64 + hd) = lo.u;
+                        }
                     }
                 }
         }
@@ -278,6 +284,7 @@ template <typename T> int launch_flash(const AttnParams& p, hipStream_t s)
                "attention: V^T rows must be padded to a multiple of 64 keys and 16-byte aligned (ldvt=%ld Sk=%d)", p.ldvt, p.Sk);
     UW_REQUIRE(!p.causal || p.Sk >= p.Sq, "attention: causal needs Sk >= Sq");
     UW_REQUIRE((p.ldo * sizeof(T)) % 8 == 0, "attention: output rows must be 8-byte aligned");
+    UW_REQUIRE(!p.o_split || (sizeof(T) == 2 && p.ldo >= 2l * p.H * 64), "attention: split output is a bf16 row of 2 * H * 64 elements");
     const dim3 grid((p.Sq + 127) / 128, p.H, p.B);
     hipLaunchKernelGGL((attention_kernel<T, false>), grid, dim3(256), 4 * Lay<T>::TILE, s, p, ProbParams());
     UW_LAUNCH_CHECK();

@@ -182,3 +182,18 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Function attributes (the dynamic LDS limit) are kept per device: one flag per device ordinal, so a process that
+// owns contexts on several GPUs sets the attribute on each of them.  first_use() is true once per device.
+struct PerDeviceFlag {
+    bool seen[64] = {};
+    bool first_use()
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return true;
+        dev &= 63;
+        if (seen[dev]) return false;
+        seen[dev] = true;
+        return true;
+    }
+};

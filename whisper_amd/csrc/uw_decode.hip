@@ -49,6 +49,14 @@ __device__ __forceinline__ uint4 ld_stream(const void* p)
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// attention output element: the compute-dtype value, plus (split activations) what rounding it dropped in the lo plane
+template <typename T> __device__ __forceinline__ void store_split(void* out, void* out_lo, long at, float v)
+{
+    const T hi = from_f32<T>(v);
+    ((T*)out)[at] = hi;
+    if (out_lo) ((T*)out_lo)[at] = from_f32<T>(v - to_f32<T>(hi));
+}
+
 // sum over the LPR lanes that share a row
 template <typename T> __device__ __forceinline__ float row_sum(float v)
 {
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(64 * NW) void cross_decode_kernel(CrossDecodeParams
 #pragma unroll
         for (int w = 0; w < NW; ++w) o += part[w * 64 + tid];
         const long at = p.out_packed ? frag_elem_offset<T>(b, h * 64 + tid, p.d) : (long)b * p.d + h * 64 + tid;
-        ((T*)p.out)[at] = from_f32<T>(o);
+        store_split<T>(p.out, p.out_lo, at, o);
     }
 }
 
@@ -309,7 +317,7 @@ __global__ __launch_bounds__(256) void cross_combine_kernel(CrossDecodeParams p)
         float o = 0.f;
         for (int z = 0; z < p.n_split; ++z) o += ws[z * 66 + 2 + tid] * __expf(ws[z * 66] - M);
         const long at = p.out_packed ? frag_elem_offset<T>(b, h * 64 + tid, p.d) : (long)b * p.d + h * 64 + tid;
-        ((T*)p.out)[at] = from_f32<T>(o * inv);
+        store_split<T>(p.out, p.out_lo, at, o * inv);
     }
     const int slot = p.sel_slot[h];
     if (p.rows && slot >= 0) {
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
     if (tid < 64) {
         const float o = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
         const long at = p.out_packed ? frag_elem_offset<T>(b, h * 64 + tid, p.d) : (long)b * p.d + h * 64 + tid;
-        ((T*)p.out)[at] = from_f32<T>(o);
+        store_split<T>(p.out, p.out_lo, at, o);
     }
 }
 

@@ -10,7 +10,8 @@ namespace {
 template <typename T, int NI>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, T* __restrict__ y,
                                                         float* __restrict__ y32, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, long rows, int d, int packed, int x_layout)
+                                                        const float* __restrict__ beta, long rows, int d, int packed, int x_layout,
+                                                        int split)
 {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -54,22 +55,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (y32) ((f32x4*)(y32 + row * d))[c] = o;
             if (y) {
                 // four consecutive columns never straddle a 16-byte chunk, so they stay contiguous when packed
-                T* dst = packed ? y + frag_elem_offset<T>(row, c * 4, d) : y + row * d + c * 4;
+                T* dst = packed ? y + frag_elem_offset<T>(row, c * 4, d) : y + row * (split ? 2 * d : d) + c * 4;
                 if constexpr (sizeof(T) == 4) {
                     *(f32x4*)dst = o;
                 } else {
-                    union { bf16_t h[4]; uint2 u; } pk;
+                    union { bf16_t h[4]; uint2 u; } pk, lo;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) pk.h[k] = (bf16_t)o[k];
+                    for (int k = 0; k < 4; ++k) {
+                        pk.h[k] = (bf16_t)o[k];
+                        lo.h[k] = (bf16_t)(o[k] - (float)pk.h[k]);
+                    }
                     *(uint2*)dst = pk.u;
+                    if (split) *(uint2*)(dst + d) = lo.u;
                 }
             }
         }
     }
 }
 
-// one wave per weight row: LayerNorm scale folded into the row, shift folded into the bias, row sum of the
-// rounded row kept for the mean correction
+// one wave per weight row: the row in the compute dtype, the LayerNorm shift folded into the bias, and the
+// gamma-weighted sum of the rounded row for the mean correction
 template <typename T>
 __global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ w, const float* __restrict__ bias_in,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -80,16 +85,15 @@ __global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __rest
     if (n >= N) return;
     float sb = 0.f, sw = 0.f;
     for (int k = lane; k < K; k += 64) {
-        const float wv = w[(long)n * K + k];
-        const T r = from_f32<T>(wv * scale * gamma[k]);
+        const T r = from_f32<T>(w[(long)n * K + k] * scale);
         dst[(long)n * K + k] = r;
-        sw += to_f32<T>(r);
-        sb += wv * beta[k];
+        sw += to_f32<T>(r) * gamma[k];
+        sb += to_f32<T>(r) * beta[k];
     }
     sb = wave_sum(sb);
     sw = wave_sum(sw);
     if (lane == 0) {
-        bias_out[n] = scale * ((bias_in ? bias_in[n] : 0.f) + sb);
+        bias_out[n] = scale * (bias_in ? bias_in[n] : 0.f) + sb;
         wsum[n] = sw;
     }
 }
@@ -208,16 +212,17 @@ inline int stream_grid(long n, int block) { return (int)(n / block + 1 < 4096 ? 
 }  // namespace
 
 int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* gamma, const float* beta, long rows,
-                 int d, hipStream_t s, int packed, int x_layout)
+                 int d, hipStream_t s, int packed, int x_layout, int split)
 {
+    UW_REQUIRE(!split || (dtype == UW_BF16 && !packed), "layernorm: split output is a row-major bf16 form");
     UW_REQUIRE(d % 4 == 0 && d <= 2048 && rows > 0, "layernorm: d=%d rows=%ld unsupported", d, rows);
     UW_REQUIRE(!packed || d % (dtype == UW_F32 ? 16 : 32) == 0, "layernorm: packed output needs d=%d to be a multiple of 64 bytes", d);
     const dim3 grid((unsigned)((rows + 3) / 4));
     const int ni = (d / 4 + 63) / 64;
 #define UW_LN_LAUNCH(NI)                                                                                                         \
     do {                                                                                                                         \
-        if (dtype == UW_F32) hipLaunchKernelGGL((layernorm_kernel<float, NI>), grid, dim3(256), 0, s, x, (float*)y, y32, gamma, beta, rows, d, packed, x_layout); \
-        else hipLaunchKernelGGL((layernorm_kernel<bf16_t, NI>), grid, dim3(256), 0, s, x, (bf16_t*)y, y32, gamma, beta, rows, d, packed, x_layout);    \
+        if (dtype == UW_F32) hipLaunchKernelGGL((layernorm_kernel<float, NI>), grid, dim3(256), 0, s, x, (float*)y, y32, gamma, beta, rows, d, packed, x_layout, split); \
+        else hipLaunchKernelGGL((layernorm_kernel<bf16_t, NI>), grid, dim3(256), 0, s, x, (bf16_t*)y, y32, gamma, beta, rows, d, packed, x_layout, split);    \
     } while (0)
     if (ni <= 1) UW_LN_LAUNCH(1);
     else if (ni <= 2) UW_LN_LAUNCH(2);

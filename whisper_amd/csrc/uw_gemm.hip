@@ -52,12 +52,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p)
         srcB[i] = B + (long)gn * p.ldb + c * E;
     }
     const unsigned lds_base = lds_addr_of(smem) + __builtin_amdgcn_readfirstlane(wave) * 1024;
+    // split activations: the other operand (the weights) repeats after kwrap elements of K
+    const int wrap_a = p.kwrap_a ? p.kwrap_a / KT : 0x7fffffff, wrap_b = p.kwrap_b ? p.kwrap_b / KT : 0x7fffffff;
     auto stage = [&](int kt, int buf) {
         const unsigned a_dst = lds_base + buf * 2 * TILE_BYTES, b_dst = a_dst + TILE_BYTES;
+        const int kta = kt >= wrap_a ? kt - wrap_a : kt, ktb = kt >= wrap_b ? kt - wrap_b : kt;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            glds16(srcA[i] + (long)kt * KT, a_dst + i * 4096);
-            glds16(srcB[i] + (long)kt * KT, b_dst + i * 4096);
+            glds16(srcA[i] + (long)kta * KT, a_dst + i * 4096);
+            glds16(srcB[i] + (long)ktb * KT, b_dst + i * 4096);
         }
     };
 
@@ -122,9 +125,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p)
                 if constexpr (sizeof(TC) == 4) {
                     *(f32x4*)((float*)C + c_off(p, m, n)) = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
-                    union { bf16_t h[4]; uint2 u; } pk;
-                    pk.h[0] = (bf16_t)v[0]; pk.h[1] = (bf16_t)v[1]; pk.h[2] = (bf16_t)v[2]; pk.h[3] = (bf16_t)v[3];
+                    union { bf16_t h[4]; uint2 u; } pk, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        pk.h[r] = (bf16_t)v[r];
+                        lo.h[r] = (bf16_t)(v[r] - (float)pk.h[r]);
+                    }
                     *(uint2*)((bf16_t*)C + c_off(p, m, n)) = pk.u;
+                    if (p.c_split) *(uint2*)((bf16_t*)C + c_off(p, m, n) + p.N) = lo.u;
                 }
             } else {
 #pragma unroll
@@ -132,7 +140,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmParams p)
                     if (n + r >= p.N) break;
                     float x = v[r];
                     if (R) x += R[(long)m * p.ldr + n + r];
-                    C[c_off(p, m, n) + r] = from_f32<TC>(x);
+                    const TC hi = from_f32<TC>(x);
+                    C[c_off(p, m, n) + r] = hi;
+                    if (p.c_split) C[c_off(p, m, n) + r + p.N] = from_f32<TC>(x - to_f32<TC>(hi));
                 }
             }
         }
@@ -144,6 +154,10 @@ template <typename T, typename TC> int launch(const GemmParams& p, hipStream_t s
     constexpr int KT = KB / (int)sizeof(T);
     UW_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.batch > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
     UW_REQUIRE(p.K % KT == 0, "gemm: K=%d must be a multiple of %d", p.K, KT);
+    UW_REQUIRE(p.kwrap_a % KT == 0 && p.kwrap_b % KT == 0 && (!p.kwrap_a || p.K == 2 * p.kwrap_a) && (!p.kwrap_b || p.K == 2 * p.kwrap_b),
+               "gemm: split operands need K=%d to be twice the wrap length, a multiple of %d", p.K, KT);
+    UW_REQUIRE(!p.c_split || (sizeof(TC) == 2 && !p.c_group && !p.residual && p.N % 4 == 0 && p.ldc >= 2 * (long)p.N),
+               "gemm: split output is a bf16 row of 2N=%d elements without residual", 2 * p.N);
     UW_REQUIRE((p.lda * sizeof(T)) % 16 == 0 && (p.ldb * sizeof(T)) % 16 == 0 && (p.sA * sizeof(T)) % 16 == 0 &&
                    (p.sB * sizeof(T)) % 16 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0,
                "gemm: operand rows must be 16-byte aligned");
@@ -347,10 +361,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     const T* baseA = A + (long)m0 * p.lda;
     const T* baseB = B + (long)n0 * p.ldb;
+    // split activations: the other operand (the weights) repeats after kwrap elements of K
+    const int wrap_a = p.kwrap_a ? p.kwrap_a / KT : 0x7fffffff, wrap_b = p.kwrap_b ? p.kwrap_b / KT : 0x7fffffff;
     auto stage = [&](int kt, int st) {
         const unsigned a_dst = lds_base + st * STAGE3, b_dst = a_dst + A3_BYTES;
-        const T* ka = baseA + (long)kt * KT;
-        const T* kb = baseB + (long)kt * KT;
+        const T* ka = baseA + (long)(kt >= wrap_a ? kt - wrap_a : kt) * KT;
+        const T* kb = baseB + (long)(kt >= wrap_b ? kt - wrap_b : kt) * KT;
         glds16_sv(ka, offA[0], a_dst);
         glds16_sv(ka, offA[1], a_dst + 8192);
         glds16_sv(kb, offB, b_dst);
@@ -463,8 +479,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                     for (int r = 0; r < 8; ++r) pk.h[r] = (bf16_t)v[r];
                     STORE16_NT((bf16_t*)C + c_off(p, m, n), __builtin_bit_cast(f32x4, pk.u));
+                    if (p.c_split) {
+                        union { bf16_t h[8]; uint4 u; } lo;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) lo.h[r] = (bf16_t)(v[r] - (float)pk.h[r]);
+                        STORE16_NT((bf16_t*)C + c_off(p, m, n) + p.N, __builtin_bit_cast(f32x4, lo.u));
+                    }
                 } else {
-                    for (int r = 0; r < 8 && n + r < p.N; ++r) C[c_off(p, m, n) + r] = from_f32<TC>(v[r]);
+                    for (int r = 0; r < 8 && n + r < p.N; ++r) {
+                        const TC hi = from_f32<TC>(v[r]);
+                        C[c_off(p, m, n) + r] = hi;
+                        if (p.c_split) C[c_off(p, m, n) + r + p.N] = from_f32<TC>(v[r] - to_f32<TC>(hi));
+                    }
                 }
             }
         }
@@ -475,6 +501,10 @@ template <typename T, typename TC> int launch_duo(const GemmParams& p, hipStream
 {
     constexpr int KT = K3_ROW / (int)sizeof(T);
     UW_REQUIRE(p.K % KT == 0, "gemm: K=%d must be a multiple of %d", p.K, KT);
+    UW_REQUIRE(p.kwrap_a % KT == 0 && p.kwrap_b % KT == 0 && (!p.kwrap_a || p.K == 2 * p.kwrap_a) && (!p.kwrap_b || p.K == 2 * p.kwrap_b),
+               "gemm: split operands need K=%d to be twice the wrap length, a multiple of %d", p.K, KT);
+    UW_REQUIRE(!p.c_split || (sizeof(TC) == 2 && !p.c_group && !p.residual && p.N % 8 == 0 && p.ldc >= 2 * (long)p.N),
+               "gemm: split output is a bf16 row of 2N=%d elements without residual", 2 * p.N);
     UW_REQUIRE((p.lda * sizeof(T)) % 16 == 0 && (p.ldb * sizeof(T)) % 16 == 0 && (p.sA * sizeof(T)) % 16 == 0 &&
                    (p.sB * sizeof(T)) % 16 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0,
                "gemm: operand rows must be 16-byte aligned");
@@ -483,11 +513,9 @@ template <typename T, typename TC> int launch_duo(const GemmParams& p, hipStream
     UW_REQUIRE((long)B2M * p.lda * (long)sizeof(T) < (1l << 32) && (long)B2N * p.ldb * (long)sizeof(T) < (1l << 32),
                "gemm: operand row stride too large for 32-bit tile offsets");
     const size_t lds = (size_t)NSTAGE3 * STAGE3;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceFlag attr_set;
+    if (attr_set.first_use())
         UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_duo_kernel<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     const long total = tiles * p.batch;
     const unsigned grid = (unsigned)total;
     hipLaunchKernelGGL((gemm_tn_duo_kernel<T, TC>), dim3(grid), dim3(512), lds, s, p);
@@ -499,17 +527,16 @@ template <typename T, typename TC> int launch_big(const GemmParams& p, hipStream
 {
     constexpr int KT = KB / (int)sizeof(T);
     UW_REQUIRE(p.K % KT == 0, "gemm: K=%d must be a multiple of %d", p.K, KT);
+    UW_REQUIRE(!p.kwrap_a && !p.kwrap_b && !p.c_split, "gemm: split operands are not supported with an activation plus residual");
     UW_REQUIRE((p.lda * sizeof(T)) % 16 == 0 && (p.ldb * sizeof(T)) % 16 == 0 && (p.sA * sizeof(T)) % 16 == 0 &&
                    (p.sB * sizeof(T)) % 16 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0,
                "gemm: operand rows must be 16-byte aligned");
     const long tiles = (long)ceil_div(p.M, B2M) * ceil_div(p.N, B2N);
     UW_REQUIRE(tiles < (1l << 31) && p.batch < 65536, "gemm: grid too large");
     const size_t lds = (size_t)NSTAGE2 * STAGE2;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceFlag attr_set;
+    if (attr_set.first_use())
         UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_big_kernel<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     hipLaunchKernelGGL((gemm_tn_big_kernel<T, TC>), dim3((unsigned)tiles, (unsigned)p.batch), dim3(512), lds, s, p);
     UW_LAUNCH_CHECK();
     return UW_OK;
@@ -526,7 +553,9 @@ constexpr int SK_WAVES = 8;
 constexpr int SK_ROUND = 3;      // K-steps per register buffer; two buffers are in flight
 constexpr int SK_ROUND_LN = 2;   // same for the LayerNorm-fused form, whose f32 operand takes twice the registers
 
-template <typename T, typename TC, int MT, int NT, bool PACKED>
+// HILO: A arrives as two fragment-major planes, hi and lo (split activations, see GemmParams); every weight block is
+// multiplied with both, the matrix cores being idle in this kernel anyway.
+template <typename T, typename TC, int MT, int NT, bool PACKED, bool HILO = false>
 __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -548,6 +577,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
     const long a_bytes = PACKED ? (long)((p.M + 15) & ~15) * p.K * ES : (long)p.M * p.lda * ES;
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(HILO ? p.A_lo : p.A), 0, (int)a_bytes, 0x00020000);
     int woff[NT], aoff[MT];
     if constexpr (PACKED) {
         const int n_blocks = (p.N + 15) >> 4, m_blocks = (p.M + 15) >> 4;
@@ -601,7 +631,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
     };
     // Rounds of SK_ROUND K-steps, double-buffered in registers: the loads of round r+1 are issued before the
     // MFMAs of round r, so a wave pays the memory latency once, not once per round.
-    uint4 wv[2][SK_ROUND][NT], av[2][SK_ROUND][MT];
+    uint4 wv[2][SK_ROUND][NT], av[2][SK_ROUND][HILO ? 2 * MT : MT];
     auto load_round = [&](int buf, int s) {
 #pragma unroll
         for (int r = 0; r < SK_ROUND; ++r) {
@@ -609,7 +639,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wv[buf][r][nt] = ld(rsW, woff[nt], koff);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[buf][r][mt] = ld(rsA, aoff[mt], koff);
+            for (int mt = 0; mt < MT; ++mt) {
+                av[buf][r][mt] = ld(rsA, aoff[mt], koff);
+                if constexpr (HILO) av[buf][r][MT + mt] = ld(rsA2, aoff[mt], koff);
+            }
         }
     };
     auto mma_round = [&](int buf, int s) {
@@ -619,7 +652,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) mma16<T>(wv[buf][r][nt], av[buf][r][mt], acc[mt][nt]);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        mma16<T>(wv[buf][r][nt], av[buf][r][mt], acc[mt][nt]);
+                        if constexpr (HILO) mma16<T>(wv[buf][r][nt], av[buf][r][MT + mt], acc[mt][nt]);
+                    }
             }
         }
     };
@@ -674,12 +710,14 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
 
 // ------------------------------------------------------------------------------------------------
 // Skinny form with the LayerNorm in front of the linear layer fused in.  A is the f32 residual stream x in the
-// step's x layout, W holds gamma-scaled weights (fragment-major), and
-//     LN(x) W^T + b  =  rstd * (x W'^T - mean * wsum) + b',      W' = W diag(gamma), b' = b + W beta, wsum = W' 1
-// so the product runs on x as it is and the row statistics -- which the workgroup gets for free from the very
-// operand blocks it loads, every wave summing its K slice -- enter only in the epilogue.  For bf16 compute x is
-// split into a high and a low bf16 part (two MFMAs per block, the matrix cores idle in this kernel anyway), which
-// keeps ~16 mantissa bits of x: more than rounding a normalised row to bf16 keeps.
+// step's x layout, W the layer's own weights (fragment-major, compute dtype), and
+//     LN(x) W^T + b  =  rstd * ((x * gamma) W^T - mean * wsum) + b',      b' = b + W beta,  wsum[n] = sum_k gamma[k] W[n][k]
+// so the product runs on x scaled by gamma as it is loaded, and the row statistics -- which the workgroup gets for
+// free from the very operand blocks it loads, every wave summing its K slice -- enter only in the epilogue.  gamma
+// is applied to the f32 operand, not folded into the weights: W stays the rounding of the model's weight, the same
+// matrix the multi-token kernels multiply with.  For bf16 compute x * gamma is split into a high and a low bf16 part
+// (two MFMAs per block, the matrix cores idle in this kernel anyway), which keeps ~16 mantissa bits: more than
+// rounding a normalised row to bf16 keeps.
 template <typename T, typename TC, int MT, int NT>
 __global__ __launch_bounds__(64 * SK_WAVES) void gemm_step_ln_kernel(GemmParams p)
 {
@@ -690,6 +728,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_step_ln_kernel(GemmParams 
     constexpr int A_STEP = 1024 * AH;                    // bytes of x per (row block, K step)
     f32x4* part = (f32x4*)smem;                          // [SK_WAVES][MT * NT][64]
     float* stat = (float*)(part + SK_WAVES * MT * NT * 64);   // [SK_WAVES][MT][16][2]
+    float* gam = stat + SK_WAVES * MT * 16 * 2;               // [K] LayerNorm scale
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
@@ -756,18 +795,24 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_step_ln_kernel(GemmParams 
                         const float f0 = __uint_as_float(a.x), f1 = __uint_as_float(a.y), f2 = __uint_as_float(a.z), f3 = __uint_as_float(a.w);
                         sx[mt] += (f0 + f1) + (f2 + f3);
                         sxx[mt] += (f0 * f0 + f1 * f1) + (f2 * f2 + f3 * f3);
+                        const f32x4 g = *(const f32x4*)(gam + (s + r) * KS + fg * 4);
+                        const uint4 ag = make_uint4(__float_as_uint(f0 * g[0]), __float_as_uint(f1 * g[1]), __float_as_uint(f2 * g[2]),
+                                                    __float_as_uint(f3 * g[3]));
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) mma16<T>(wv[buf][r][nt], a, acc[mt][nt]);
+                        for (int nt = 0; nt < NT; ++nt) mma16<T>(wv[buf][r][nt], ag, acc[mt][nt]);
                     } else {
                         const uint4 a0 = xv[buf][r][mt][0], a1 = xv[buf][r][mt][AH - 1];
                         const float f[8] = {__uint_as_float(a0.x), __uint_as_float(a0.y), __uint_as_float(a0.z), __uint_as_float(a0.w),
                                             __uint_as_float(a1.x), __uint_as_float(a1.y), __uint_as_float(a1.z), __uint_as_float(a1.w)};
+                        const f32x4 g0 = *(const f32x4*)(gam + (s + r) * KS + fg * 8), g1 = *(const f32x4*)(gam + (s + r) * KS + fg * 8 + 4);
+                        const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
                         union { bf16_t h[8]; uint4 u; } hi, lo;
                         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            hi.h[e] = (bf16_t)f[e];
-                            lo.h[e] = (bf16_t)(f[e] - (float)hi.h[e]);
+                            const float fgm = f[e] * g[e];
+                            hi.h[e] = (bf16_t)fgm;
+                            lo.h[e] = (bf16_t)(fgm - (float)hi.h[e]);
                             s1 += f[e];
                             s2 = fmaf(f[e], f[e], s2);
                         }
@@ -783,8 +828,12 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_step_ln_kernel(GemmParams 
             }
         }
     };
+    if (s_begin < s_end) load_round(0, s_begin);
+    // the scale vector goes through LDS (every lane needs the 4 or 8 entries of its K chunk at every step); the
+    // first round of operand loads is already in flight behind this barrier
+    for (int i = tid; i < (p.K >> 2); i += 64 * SK_WAVES) ((f32x4*)gam)[i] = ((const f32x4*)p.gamma)[i];
+    __syncthreads();
     if (s_begin < s_end) {
-        load_round(0, s_begin);
         for (int s = s_begin; s < s_end; s += 2 * SK_ROUND_LN) {
             if (s + SK_ROUND_LN < s_end) load_round(1, s + SK_ROUND_LN);
             __builtin_amdgcn_sched_barrier(0);
@@ -840,6 +889,12 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_step_ln_kernel(GemmParams 
             union { bf16_t h[4]; uint2 u; } pk;
             pk.h[0] = (bf16_t)v[0]; pk.h[1] = (bf16_t)v[1]; pk.h[2] = (bf16_t)v[2]; pk.h[3] = (bf16_t)v[3];
             *(uint2*)((bf16_t*)C + at) = pk.u;
+            if (p.C_lo) {   // split output: what rounding to bf16 dropped goes to the lo plane
+                union { bf16_t h[4]; uint2 u; } lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lo.h[r] = (bf16_t)(v[r] - (float)pk.h[r]);
+                *(uint2*)((bf16_t*)p.C_lo + at) = lo.u;
+            }
         }
     } else {
 #pragma unroll
@@ -875,10 +930,22 @@ template <typename T, typename TC, int MT, int NT> int launch_skinny_mt(const Ge
     return UW_OK;
 }
 
+template <typename T, typename TC, int MT, int NT> int launch_skinny_hilo(const GemmParams& p, hipStream_t s)
+{
+    const size_t lds = (size_t)SK_WAVES * MT * NT * 64 * sizeof(f32x4);
+    const dim3 grid((p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT, NT, true, true>), grid, dim3(64 * SK_WAVES), lds, s, p);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
+}
+
 template <typename T, typename TC, int MT, int NT> int launch_step_ln_mt(const GemmParams& p, hipStream_t s)
 {
-    const size_t lds = (size_t)SK_WAVES * MT * NT * 64 * sizeof(f32x4) + (size_t)SK_WAVES * MT * 16 * 2 * sizeof(float);
+    const size_t lds = (size_t)SK_WAVES * MT * NT * 64 * sizeof(f32x4) + (size_t)SK_WAVES * MT * 16 * 2 * sizeof(float) + (size_t)p.K * sizeof(float);
     const dim3 grid((p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
+    static PerDeviceFlag attr_set;
+    if (lds > 64 * 1024 && attr_set.first_use())
+        UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_step_ln_kernel<T, TC, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
     hipLaunchKernelGGL((gemm_step_ln_kernel<T, TC, MT, NT>), grid, dim3(64 * SK_WAVES), lds, s, p);
     UW_LAUNCH_CHECK();
     return UW_OK;
@@ -887,10 +954,11 @@ template <typename T, typename TC, int MT, int NT> int launch_step_ln_mt(const G
 template <typename T, typename TC> int launch_step_ln(const GemmParams& p, hipStream_t s)
 {
     constexpr int KS = 64 / (int)sizeof(T);
-    UW_REQUIRE(p.M > 0 && p.M <= 128 && p.N > 0 && p.K > 0 && p.batch == 1 && p.ab_packed && p.wsum && !p.residual && !p.c_group,
+    UW_REQUIRE(p.M > 0 && p.M <= 128 && p.N > 0 && p.K > 0 && p.K <= 4096 && p.batch == 1 && p.ab_packed && p.wsum && p.gamma && !p.residual && !p.c_group,
                "LayerNorm-fused gemm: unsupported arguments (M=%d)", p.M);
     UW_REQUIRE(p.K % KS == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0, "LayerNorm-fused gemm: K=%d or alignment", p.K);
     UW_REQUIRE(!p.c_packed || (sizeof(TC) == sizeof(T) && p.N % KS == 0), "LayerNorm-fused gemm: packed output needs N=%d a multiple of %d", p.N, KS);
+    UW_REQUIRE(!p.C_lo || (p.c_packed && sizeof(TC) == 2), "LayerNorm-fused gemm: a lo plane goes with packed bf16 output");
     // measured on MI355X at M = 128: the f32 operand and its bf16 split are amortised over four column tiles when
     // N is wide; a narrow N keeps 16-row workgroups so that the grid still covers most CUs
     if (p.M <= 16) return p.N >= 2048 ? launch_step_ln_mt<T, TC, 1, 2>(p, s) : launch_step_ln_mt<T, TC, 1, 1>(p, s);
@@ -913,6 +981,15 @@ template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStr
                "skinny gemm: x-layout output needs f32 C, N=%d a multiple of %d and a residual of the same shape", p.N, KS);
     UW_REQUIRE(!p.c_packed || (sizeof(TC) == sizeof(T) && p.N % KS == 0 && !p.c_group),
                "skinny gemm: packed output needs the compute dtype and N=%d a multiple of %d", p.N, KS);
+    if (p.A_lo) {
+        if constexpr (sizeof(T) == 2) {
+            UW_REQUIRE(p.ab_packed && ((uintptr_t)p.A_lo % 16) == 0, "skinny gemm: split A needs fragment-major operands");
+            if (p.M <= 16) return launch_skinny_hilo<T, TC, 1, 1>(p, s);
+            return launch_skinny_hilo<T, TC, 2, 1>(p, s);
+        } else {
+            UW_REQUIRE(false, "skinny gemm: split A is a bf16 form");
+        }
+    }
     // 16 x 16 output tiles per workgroup: few rows per workgroup keep its activation traffic small; wide N takes
     // more tiles per workgroup so the grid stays near one workgroup per CU
     if (p.M <= 16) return p.N >= 2048 ? launch_skinny_mt<T, TC, 1, 2>(p, s) : launch_skinny_mt<T, TC, 1, 1>(p, s);

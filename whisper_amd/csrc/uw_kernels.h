@@ -22,10 +22,21 @@ struct GemmParams {
     int act = 0;        // 0 none, 1 GELU(erf)
     int ab_packed = 0, c_packed = 0;  // fragment-major operands / output (skinny form only)
     int c_xlayout = 0;                // skinny form: f32 C and residual are in the step's x layout (x_elem_offset)
-    // skinny form, LayerNorm fused: A is the f32 residual stream in the x layout, B holds gamma-scaled weights,
-    // bias holds bias + W.beta, wsum[n] = sum_k B[n][k]; C = rstd * (A.B^T - mean * wsum) + bias
+    // skinny form, LayerNorm fused: A is the f32 residual stream in the x layout, B the layer's weights, gamma [K] the
+    // LayerNorm scale, bias holds bias + W.beta, wsum[n] = sum_k gamma[k] B[n][k];
+    // C = rstd * ((A * gamma).B^T - mean * wsum) + bias
     int ln_fused = 0;
     const float* wsum = nullptr;
+    const float* gamma = nullptr;
+    // Split activations (bf16 compute only).  A value v is carried as hi = bf16(v) and lo = bf16(v - hi), which keeps
+    // about 16 mantissa bits; a product against W then runs as hi.W + lo.W into the same f32 accumulator.
+    //   tile kernels: the operand row is [hi | lo] (2K elements); the OTHER operand repeats after kwrap elements of K
+    //                 (kwrap_b: B repeats, kwrap_a: A repeats), so the weights are not duplicated in memory.
+    //                 c_split: C (bf16) is written as [hi | lo], lo at column n + N (ldc >= 2N).
+    //   skinny form:  A_lo / C_lo are the lo planes of fragment-major A / C.
+    int kwrap_a = 0, kwrap_b = 0, c_split = 0;
+    const void* A_lo = nullptr;
+    void* C_lo = nullptr;
     long c_group = 0;   // 0: C[m][n] at m*ldc + n.  Else columns are stored in groups of 64 (one attention head):
                         // C[m][n] at (n / 64) * c_group + m * ldc + (n % 64), ldc = 64 for a head-contiguous cache
 };
@@ -41,10 +52,11 @@ int uw_pack_frag(int dtype, const void* src, long ld, void* dst, int R, int K, h
 // ---- uw_elementwise.hip -----------------------------------------------------------------------
 // y[r][:] = LayerNorm(x[r][:]) * gamma + beta, eps 1e-5.  y in dtype; y32 (optional) also gets f32.
 // packed: y is written fragment-major (frag_elem_offset), the A operand of the decode-step GEMMs
+// split (bf16 only): row r of y is [hi | lo], 2d elements (see GemmParams)
 int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* gamma, const float* beta, long rows,
-                 int d, hipStream_t s, int packed = 0, int x_layout = 0);
-// LayerNorm folded into the following linear layer (rows of w): dst[n][k] = T(w[n][k] * scale * gamma[k]),
-// bias_out[n] = scale * (bias_in[n] + sum_k w[n][k] * beta[k]), wsum[n] = sum_k float(dst[n][k])
+                 int d, hipStream_t s, int packed = 0, int x_layout = 0, int split = 0);
+// Operands of a LayerNorm-fused product (rows of w): dst[n][k] = T(w[n][k] * scale), the weights as every other kernel
+// holds them; bias_out[n] = scale * bias_in[n] + sum_k float(dst[n][k]) * beta[k]; wsum[n] = sum_k float(dst[n][k]) * gamma[k]
 int uw_fold_layernorm(int dtype, const float* w, const float* bias_in, const float* gamma, const float* beta, float scale,
                       void* dst, float* bias_out, float* wsum, int N, int K, hipStream_t s);
 // dst (dtype) = src (f32) * scale, n elements
@@ -74,6 +86,7 @@ struct AttnParams {
     int B = 0, H = 0, Sq = 0, Sk = 0;
     int causal = 0;            // query i sees keys <= i + (Sk - Sq)
     const int32_t* sq_len = nullptr;  // optional per-window valid query count (<= Sq); rows beyond are skipped
+    int o_split = 0;           // bf16 only: O rows are [hi | lo], lo at column H*64 + c (ldo >= 2*H*64)
 };
 int uw_flash_attention(int dtype, const AttnParams& p, hipStream_t s);
 
@@ -99,6 +112,7 @@ struct SelfDecodeParams {
     void* kcache = nullptr;     // this layer's cache: element (b, h, r, e) at b*cache_sB + h*cache_sH + r*ld_cache + e
     void* vcache = nullptr;
     void* out = nullptr;        // [B][d]
+    void* out_lo = nullptr;     // bf16, fragment-major only: lo plane of the split output (see GemmParams)
     int out_packed = 0;         // out in the fragment-major layout
     const int32_t* pos = nullptr;     // per window position of the current token
     const int32_t* active = nullptr;  // per window: 0 = finished (skip)
@@ -113,6 +127,7 @@ struct CrossDecodeParams {
     const void* K = nullptr;   // this layer: element (b, h, r, e) at b*kv_sB + h*kv_sH + r*ld_kv + e
     const void* V = nullptr;
     void* out = nullptr;       // [B][d]
+    void* out_lo = nullptr;    // bf16, fragment-major only: lo plane of the split output (see GemmParams)
     int out_packed = 0;        // out in the fragment-major layout
     float* rows = nullptr;     // attention rows [B][n_sel][n_rows_max][S] or null
     long rows_sB = 0, rows_sSel = 0;
