@@ -1,15 +1,17 @@
 """GPU parity of mel, encoder, decoder, greedy decode and the end-to-end window path against the oracle.
 
 Tolerances (stated by the path's parity contract): fp32 mode logits within 1e-4 abs and greedy tokens
-identical; bf16 mode is checked teacher-forced (logits within 3e-2 abs here, the 1e-2 target is reported by
-tools/gpu_check.py per model); DTW bit-exact on equal cost matrices; mel within 5e-5 abs of the fp32 oracle.
+identical; bf16 mode is checked teacher-forced, logits within 1e-2 abs of the oracle evaluated in fp32 on the
+weights the bf16 engine holds (tests.helpers.bf16_weights: rounding the weights alone moves the fp32 oracle by about
+as much again, which no bf16-weight implementation can avoid); DTW bit-exact on equal cost matrices; mel within
+5e-5 abs of the fp32 oracle.
 """
 import numpy as np
 import pytest
 import torch
 
 from oracle import whisper_oracle as O
-from tests.helpers import MICRO_SPECIALS, synth_audio
+from tests.helpers import MICRO_SPECIALS, bf16_weights, synth_audio
 from whisper_amd import config as CFG
 from whisper_amd import engine as E
 from whisper_amd.weights import synthetic_state_dict
@@ -24,12 +26,15 @@ def micro():
     dims = CFG.dims_for("micro")
     sd = synthetic_state_dict(dims, seed=0, std=0.06)     # wide enough that tokens vary from step to step
     om = O.OracleModel(sd, dims.n_heads)
+    om_r = O.OracleModel(bf16_weights(sd), dims.n_heads)      # fp32 arithmetic on the bf16 engine's weights
     eng32 = E.Engine(dims, sd, dtype="f32", max_batch=4, align_heads=HEADS)
     engbf = E.Engine(dims, sd, dtype="bf16", max_batch=4, align_heads=HEADS)
     audio = [synth_audio(1), synth_audio(2, 300000)]
     mel = np.concatenate([O.log_mel_segment(a, dims.n_mels) for a in audio], 0)
     enc = np.concatenate([om.encode(mel[i: i + 1]) for i in range(2)], 0)
-    yield dict(dims=dims, sd=sd, om=om, f32=eng32, bf16=engbf, audio=audio, mel=mel, enc=enc)
+    enc_r = np.concatenate([om_r.encode(mel[i: i + 1]) for i in range(2)], 0)
+    yield dict(dims=dims, sd=sd, om=om, f32=eng32, bf16=engbf, audio=audio, mel=mel, enc=enc,
+               ref={"f32": om, "bf16": om_r}, enc_ref={"f32": enc, "bf16": enc_r})
     eng32.close()
     engbf.close()
 
@@ -55,16 +60,18 @@ def test_mel_matches_oracle(micro):
     assert np.abs(mel[3] + 1.5).max() < 1e-6                     # silence: log10(1e-10) = -10 -> (-10 + 4) / 4
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 1e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-4), ("bf16", 3e-2)])
 def test_encoder_matches_oracle(micro, mode, tol):
+    """Encoder states (LayerNorm outputs of unit scale; the contract's bf16 figure is for logits, where this error
+    arrives averaged over the 1500 frames)."""
     enc = micro[mode].encode(torch.from_numpy(micro["mel"]).to(DEV)).cpu().numpy()
     assert enc.shape == micro["enc"].shape
-    assert np.abs(enc - micro["enc"]).max() < tol
+    assert np.abs(enc - micro["enc_ref"][mode]).max() < tol
 
 
-@pytest.mark.parametrize("mode,tol_logits,tol_probs", [("f32", 1e-4, 1e-6), ("bf16", 3e-2, 1e-4)])
+@pytest.mark.parametrize("mode,tol_logits,tol_probs", [("f32", 1e-4, 1e-6), ("bf16", 1e-2, 1e-4)])
 def test_decoder_forward_matches_oracle(micro, mode, tol_logits, tol_probs):
-    eng, om, enc = micro[mode], micro["om"], micro["enc"]
+    eng, om, enc = micro[mode], micro["ref"][mode], micro["enc"]
     eng.cross_kv(2, torch.from_numpy(enc).to(DEV))
     ids = [[824, 825, 826, 924, 5, 17, 900, 3, 321, 77, 12], [824, 826, 924, 9, 9, 9, 1000, 1, 2, 3, 4]]
     out = eng.decoder_forward(torch.tensor(ids, dtype=torch.int32), logits_all=True, logits_last=True, cross_probs=True)
@@ -77,10 +84,10 @@ def test_decoder_forward_matches_oracle(micro, mode, tol_logits, tol_probs):
         assert np.allclose(got.sum(-1), 1.0, atol=1e-4)
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 1e-4), ("bf16", 1e-2)])
 def test_decode_step_continues_a_prefix(micro, mode, tol):
     """KV-cached single steps after a cache-less pass over the prefix reproduce the cache-less logits."""
-    eng, om, enc = micro[mode], micro["om"], micro["enc"]
+    eng, om, enc = micro[mode], micro["ref"][mode], micro["enc"]
     eng.cross_kv(2, torch.from_numpy(enc).to(DEV))
     ids = [[824, 825, 826, 924, 5, 17, 900, 3, 321], [824, 826, 924, 9, 9, 9, 1000, 1, 2]]
     eng.decoder_forward(torch.tensor([r[:6] for r in ids], dtype=torch.int32), logits_last=True)
@@ -150,10 +157,12 @@ def test_bf16_teacher_forced_agreement(micro):
     eng.cross_kv(1, torch.from_numpy(enc[:1]).to(DEV))
     prompt = [824, 825, 826, 924]
     seq = prompt + O.greedy_reference_schedule(om, enc[:1], prompt, 36, eot=-1)
-    ref = om.decode_full(seq, enc[:1])[0]
+    ref32 = om.decode_full(seq, enc[:1])[0]
+    ref = micro["ref"]["bf16"].decode_full(seq, enc[:1])[0]
     got = eng.decoder_forward(torch.tensor([seq], dtype=torch.int32), logits_all=True)["logits_all"][0].cpu().numpy()
-    assert np.abs(got - ref).max() < 5e-2
-    agree = (got.argmax(-1) == ref.argmax(-1)).mean()
+    assert np.abs(got - ref).max() < 1e-2, np.abs(got - ref).max()
+    assert np.abs(got - ref32).max() < np.abs(ref - ref32).max() + 1e-2
+    agree = (got.argmax(-1) == ref32.argmax(-1)).mean()
     assert agree > 0.9, agree
 
 
