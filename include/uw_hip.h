@@ -114,6 +114,16 @@ int64_t uw_dtw_workspace_bytes(int B, int n_rows_max, int S);
 int uw_dtw(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, void* dir_ws, int32_t* boundaries,
            int32_t* path_i, int32_t* path_j, int32_t* path_len, void* stream);
 
+/* uw_dtw for callers that cannot allocate or hand over a workspace (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same inputs, outputs and results as
+ * uw_dtw; the direction matrix lives in a fixed 16 MiB device array inside the library (one per GPU, held until the
+ * process ends), so B * n_rows_max * ceil(S / 16) * 4 bytes must not exceed 16 MiB (e.g. 95 windows x 448 rows x 1500
+ * frames) -- larger problems are rejected with an error, use uw_dtw.  The call allocates nothing.  All calls on one GPU
+ * share the array: calls that overlap on one GPU (different streams or threads) race. */
+#define UW_DTW_STATIC_BYTES (16 << 20)
+int uw_dtw_static(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, int32_t* boundaries,
+                  int32_t* path_i, int32_t* path_j, int32_t* path_len, void* stream);
+
 /* cost matrix + DTW on the context's rows buffer: boundaries i32 [B][n_text_ctx+1]. n_text i32 [B] device.
  * boundaries[b][0] = -1 marks a window for which no path exists (see uw_dtw). */
 int uw_align(uw_ctx* ctx, const int32_t* n_text, int B, int32_t* boundaries, void* stream);

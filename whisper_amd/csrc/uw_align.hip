@@ -261,3 +261,34 @@ int uw_dtw_run(const double* cost, const int32_t* n_tok, int B, int n_rows_max, 
     UW_LAUNCH_CHECK();
     return UW_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// DTW without a caller-provided workspace and without any allocation: the direction matrix lives in a fixed
+// device array.  Each GPU holds its own copy of the array at its own address; the address is looked up once per
+// device (with that device current) and kept.  Calls on one GPU share the array, so calls that overlap on one GPU race.
+constexpr size_t DTW_STATIC_BYTES = (size_t)16 << 20;
+static __device__ __align__(256) unsigned char scratch[DTW_STATIC_BYTES];
+
+int uw_dtw_static_run(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, int32_t* boundaries,
+                      int32_t* path_i, int32_t* path_j, int32_t* path_len, hipStream_t s)
+{
+    static void* dev_ptr[64] = {};
+    UW_REQUIRE(B > 0 && n_rows_max > 0 && S > 0, "dtw: bad sizes B=%d rows=%d S=%d", B, n_rows_max, S);
+    const size_t need = (size_t)B * n_rows_max * uw_dtw_dir_words(S) * 4;
+    UW_REQUIRE(need <= DTW_STATIC_BYTES,
+               "uw_dtw_static: B=%d x rows=%d x S=%d needs %zu bytes of direction matrix, the fixed device array holds %zu; "
+               "use uw_dtw with a workspace",
+               B, n_rows_max, S, need, DTW_STATIC_BYTES);
+    int dev = 0;
+    UW_HIP_CHECK(hipGetDevice(&dev));
+    UW_REQUIRE(dev >= 0 && dev < 64, "uw_dtw_static: device ordinal %d out of range", dev);
+    if (!dev_ptr[dev]) {
+        void* ptr = nullptr;
+        UW_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        UW_REQUIRE(ptr, "uw_dtw_static: no device address for the scratch array");
+        dev_ptr[dev] = ptr;
+    }
+    // every direction word of rows < n_tok[b] is written by the forward sweep before the backtrack reads it, so what
+    // an earlier call left in the array does not need clearing
+    return uw_dtw_run(cost, n_tok, B, n_rows_max, S, (uint8_t*)dev_ptr[dev], boundaries, path_i, path_j, path_len, s);
+}

@@ -1064,6 +1064,12 @@ int uw_dtw(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int 
     return uw_dtw_run(cost, n_tok, B, n_rows_max, S, (uint8_t*)dir_ws, boundaries, path_i, path_j, path_len, (hipStream_t)stream);
 }
 
+int uw_dtw_static(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, int32_t* boundaries, int32_t* path_i,
+                  int32_t* path_j, int32_t* path_len, void* stream)
+{
+    return uw_dtw_static_run(cost, n_tok, B, n_rows_max, S, boundaries, path_i, path_j, path_len, (hipStream_t)stream);
+}
+
 int uw_align(uw_ctx* c, const int32_t* n_text, int B, int32_t* boundaries, void* stream)
 {
     RUN(check_batch(c, B));

@@ -173,3 +173,6 @@ int uw_cost_matrix_run(const float* rows, long sB, long sSel, int n_sel, const i
 // cost [B][n_rows_max][S] f64 -> boundaries [B][n_rows_max+1], optional path
 int uw_dtw_run(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, uint8_t* dir_ws,
                int32_t* boundaries, int32_t* path_i, int32_t* path_j, int32_t* path_len, hipStream_t s);
+// the same with the direction matrix in a fixed device array (no workspace argument, no allocation)
+int uw_dtw_static_run(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, int32_t* boundaries,
+                      int32_t* path_i, int32_t* path_j, int32_t* path_len, hipStream_t s);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "uw_cost_matrix": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "uw_dtw_workspace_bytes": (_i64, [C.c_int, C.c_int, C.c_int]),
     "uw_dtw": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "uw_dtw_static": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "uw_align": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp]),
     "uw_transcribe_windows": (C.c_int, [_vp, _vp, _i64, _vp, _vp, C.c_int, C.POINTER(_i32), C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
