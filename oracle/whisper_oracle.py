@@ -182,6 +182,60 @@ class OracleModel:
         return (logits, cross) if want_attn else logits
 
 
+class CachedDecoder:
+    """The same decoder math with the schedule an optimised CPU implementation would use: cross-attention K/V projected
+    once per window, self-attention K/V cached, one token per step.  NOT the reference's schedule (core.py:938-968 re-runs
+    the whole prefix every step); it exists so that the CPU baseline can also be quoted for the better schedule, and as
+    a cross-check of `decode_full` (same logits, same last-row cross-attention)."""
+
+    def __init__(self, model: OracleModel, enc: np.ndarray):
+        self.m = model
+        m, sd = model, model.sd
+        with torch.no_grad():
+            enc_t = torch.from_numpy(np.asarray(enc, dtype=np.float32)).to(m.dtype)
+            self.cross = []
+            for i in range(m.Ld):
+                p = f"model.decoder.layers.{i}.encoder_attn"
+                self.cross.append((m._heads(m._lin(enc_t, p + ".k_proj", bias=False)), m._heads(m._lin(enc_t, p + ".v_proj"))))
+        self.k = [None] * m.Ld
+        self.v = [None] * m.Ld
+        self.n = 0
+
+    def forward(self, ids: Sequence[int]):
+        """Appends `ids` at positions n .. n+len-1; returns (logits f32[len, V], per-layer cross-attention f32[H, len, 1500])."""
+        m, sd = self.m, self.m.sd
+        hd = m.d // m.H
+        with torch.no_grad():
+            ids_t = torch.as_tensor(list(ids), dtype=torch.long)[None]
+            T = ids_t.shape[1]
+            x = sd["model.decoder.embed_tokens.weight"][ids_t] + sd["model.decoder.embed_positions.weight"][self.n:self.n + T]
+            total = self.n + T
+            mask = torch.full((T, total), float("-inf"), dtype=m.dtype).triu(self.n + 1)
+            cross_w = []
+            for i in range(m.Ld):
+                p = f"model.decoder.layers.{i}"
+                h = m._ln(x, p + ".self_attn_layer_norm")
+                q = m._heads(m._lin(h, p + ".self_attn.q_proj") * hd ** -0.5)
+                k = m._heads(m._lin(h, p + ".self_attn.k_proj", bias=False))
+                v = m._heads(m._lin(h, p + ".self_attn.v_proj"))
+                self.k[i] = k if self.k[i] is None else torch.cat([self.k[i], k], dim=2)
+                self.v[i] = v if self.v[i] is None else torch.cat([self.v[i], v], dim=2)
+                w = torch.softmax(q @ self.k[i].transpose(2, 3) + mask, dim=-1)
+                x = x + m._lin((w @ self.v[i]).transpose(1, 2).reshape(x.shape), p + ".self_attn.out_proj")
+                h = m._ln(x, p + ".encoder_attn_layer_norm")
+                q = m._heads(m._lin(h, p + ".encoder_attn.q_proj") * hd ** -0.5)
+                ck, cv = self.cross[i]
+                w = torch.softmax(q @ ck.transpose(2, 3), dim=-1)
+                cross_w.append(w[0].to(torch.float32).numpy())
+                x = x + m._lin((w @ cv).transpose(1, 2).reshape(x.shape), p + ".encoder_attn.out_proj")
+                x = x + m._mlp(m._ln(x, p + ".final_layer_norm"), p)
+            x = m._ln(x, "model.decoder.layer_norm")
+            proj = sd.get("proj_out.weight", sd["model.decoder.embed_tokens.weight"])
+            logits = F.linear(x, proj)[0].to(torch.float32).numpy()
+        self.n = total
+        return logits, cross_w
+
+
 def greedy_reference_schedule(model: OracleModel, enc: np.ndarray, prompt_ids: Sequence[int],
                               max_tokens: int, eot: int) -> List[int]:
     """core.py:938-968: every step re-runs the whole decoder over the whole prefix, takes

@@ -162,3 +162,24 @@ def test_mel_floor_uses_frames_beyond_3000():
     a, b = O.log_mel_segment(quiet, 80), O.log_mel_segment(loud, 80)
     assert a.shape == b.shape == (1, 80, 3000)
     assert b.min() > a.min() + 0.1
+
+
+def test_cached_decoder_equals_cacheless_pass():
+    """The KV-cached schedule (used only for the CPU baseline's "better schedule" figure) gives the cache-less pass's
+    logits and last-row cross-attention."""
+    from whisper_amd.config import dims_for
+    from whisper_amd.weights import synthetic_state_dict
+    dims = dims_for("micro")
+    sd = synthetic_state_dict(dims, seed=0, std=0.06)
+    om = O.OracleModel(sd, dims.n_heads)
+    enc = np.random.default_rng(0).standard_normal((1, 1500, dims.d_model)).astype(np.float32)
+    ids = [824, 825, 826, 924, 5, 17, 900, 3]
+    ref, cross = om.decode_full(ids, enc, want_attn=True)
+    dec = O.CachedDecoder(om, enc)
+    lg, _ = dec.forward(ids[:5])
+    assert np.abs(lg - ref[0, :5]).max() < 1e-5
+    for t in range(5, len(ids)):
+        lg, cw = dec.forward([ids[t]])
+        assert np.abs(lg[0] - ref[0, t]).max() < 1e-5
+        for l in range(dims.dec_layers):
+            assert np.abs(cw[l][:, 0] - cross[l][0, :, t]).max() < 1e-6

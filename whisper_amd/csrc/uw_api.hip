@@ -89,6 +89,10 @@ struct uw_ctx {
     size_t prof_used = 0;
     long prof_launches = 0;
     long prof_windows = 0;             // windows summed over the launches
+    // secondary spans, sampled so that their events do not crowd the stream: 1 self-attention decode launches (one in
+    // eight), 2 the encoder pass, 3 the DTW launch
+    struct Span { std::vector<hipEvent_t> ev; size_t used = 0; long launches = 0; };
+    Span span[4];
     // side streams: disjoint window ranges decode concurrently so one range's latency-bound small kernels
     // overlap another range's bandwidth-bound cross-attention stream
     hipStream_t sub_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -424,6 +428,23 @@ int logits_from_x(uw_ctx* c, const float* x, int M, void* ln, float* logits, hip
                 split ? d : 0);
 }
 
+// brackets for the secondary spans: begin returns the event slot (or -1), end closes it
+int span_begin(uw_ctx* c, int kind, int every, hipStream_t s)
+{
+    if (!c->prof_on) return -1;
+    uw_ctx::Span& sp = c->span[kind];
+    const long n = sp.launches++;
+    if (n % every != 0 || sp.used + 2 > sp.ev.size()) return -1;
+    if (hipEventRecord(sp.ev[sp.used], s) != hipSuccess) return -1;
+    return (int)sp.used;
+}
+void span_end(uw_ctx* c, int kind, int slot, hipStream_t s)
+{
+    if (slot < 0) return;
+    uw_ctx::Span& sp = c->span[kind];
+    if (hipEventRecord(sp.ev[slot + 1], s) == hipSuccess) sp.used = (size_t)slot + 2;
+}
+
 int encoder_forward(uw_ctx* c, const float* mel, int B, hipStream_t s)
 {
     const int d = c->d, S = c->S, H = c->H, nm = c->cfg.n_mels;
@@ -632,7 +653,9 @@ int decoder_step_chunk(uw_ctx* c, int b0, int B, hipStream_t s)
         SelfDecodeParams sp;
         sp.qkv = qkv; sp.kcache = skv; sp.vcache = skv + (size_t)Tm * d * es; sp.out = att; sp.out_lo = att_lo;
         sp.pos = pos; sp.active = active; sp.ld_cache = 64; sp.cache_sB = (long)Tm * 2 * d; sp.cache_sH = (long)Tm * 64; sp.out_packed = 1; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
+        const int self_slot = span_begin(c, 1, 8, s);
         RUN(uw_self_attn_decode(c->dt, sp, s));
+        span_end(c, 1, self_slot, s);
         RUN(gemm_step(c, att, att_lo, l.self.wo_p, x, d, true, B, d, d, l.self.bo, 0, x, d, false, s));
         RUN(gemm_step_ln(c, x, l.cross.wq_p, l.cross.ln_g, l.cross.bln, l.cross.wsum, qkv, d, B, d, d, 0, false, s));
         CrossDecodeParams cp;
@@ -804,6 +827,8 @@ int uw_ctx_destroy(uw_ctx* c)
     (void)hipDeviceSynchronize();
     for (void* p : c->allocs) (void)hipFree(p);
     for (hipEvent_t e : c->prof_ev) (void)hipEventDestroy(e);
+    for (auto& sp : c->span)
+        for (hipEvent_t e : sp.ev) (void)hipEventDestroy(e);
     for (int k = 0; k < 4; ++k) {
         if (c->sub_stream[k]) (void)hipStreamDestroy(c->sub_stream[k]);
         if (c->sub_event[k]) (void)hipEventDestroy(c->sub_event[k]);
@@ -824,6 +849,16 @@ int uw_profile_begin(uw_ctx* c, int max_launches)
         hipEvent_t e;
         UW_HIP_CHECK(hipEventCreate(&e));
         c->prof_ev.push_back(e);
+    }
+    for (int k = 1; k < 4; ++k) {
+        const size_t want = k == 1 ? (size_t)max_launches / 4 + 2 : 128;
+        while (c->span[k].ev.size() < want) {
+            hipEvent_t e;
+            UW_HIP_CHECK(hipEventCreate(&e));
+            c->span[k].ev.push_back(e);
+        }
+        c->span[k].used = 0;
+        c->span[k].launches = 0;
     }
     c->prof_used = 0;
     c->prof_launches = 0;
@@ -846,6 +881,22 @@ int uw_profile_end(uw_ctx* c, int64_t* launches_total, int64_t* launches_timed, 
     if (launches_total) *launches_total = c->prof_launches;
     if (windows_total) *windows_total = c->prof_windows;
     if (launches_timed) *launches_timed = (int64_t)(c->prof_used / 2);
+    if (timed_ms) *timed_ms = ms;
+    return UW_OK;
+}
+
+int uw_profile_span(uw_ctx* c, int kind, int64_t* launches_total, int64_t* launches_timed, double* timed_ms)
+{
+    UW_REQUIRE(c && !c->prof_on && kind >= 1 && kind <= 3, "uw_profile_span: call after uw_profile_end with kind 1..3");
+    uw_ctx::Span& sp = c->span[kind];
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < sp.used; i += 2) {
+        float t = 0.f;
+        UW_HIP_CHECK(hipEventElapsedTime(&t, sp.ev[i], sp.ev[i + 1]));
+        ms += t;
+    }
+    if (launches_total) *launches_total = sp.launches;
+    if (launches_timed) *launches_timed = (int64_t)(sp.used / 2);
     if (timed_ms) *timed_ms = ms;
     return UW_OK;
 }
@@ -1076,7 +1127,10 @@ int uw_align(uw_ctx* c, const int32_t* n_text, int B, int32_t* boundaries, void*
     UW_REQUIRE(n_text && boundaries && c->n_sel > 0, "uw_align: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     RUN(uw_cost_matrix_run(c->rows, (long)c->n_sel * c->Tm * c->S, (long)c->Tm * c->S, c->n_sel, n_text, B, c->Tm, c->S, c->cost, s));
-    return uw_dtw_run(c->cost, n_text, B, c->Tm, c->S, c->dtw_ws, boundaries, nullptr, nullptr, nullptr, s);
+    const int dtw_slot = span_begin(c, 3, 1, s);
+    const int rc = uw_dtw_run(c->cost, n_text, B, c->Tm, c->S, c->dtw_ws, boundaries, nullptr, nullptr, nullptr, s);
+    span_end(c, 3, dtw_slot, s);
+    return rc;
 }
 
 int uw_transcribe_windows(uw_ctx* c, const float* audio, int64_t stride, const int32_t* n_samples, const int32_t* prompt_ids,
@@ -1091,7 +1145,9 @@ int uw_transcribe_windows(uw_ctx* c, const float* audio, int64_t stride, const i
     // the log-mel tile is parked in the (not yet used) decoder MLP scratch
     float* mel = (float*)c->e_mlp;
     RUN(uw_mel_run(c->mel_tables, audio, (long)stride, n_samples, B, mel, c->mel_max, s));
+    const int enc_slot = span_begin(c, 2, 1, s);
     RUN(encoder_forward(c, mel, B, s));
+    span_end(c, 2, enc_slot, s);
     RUN(cross_kv_project(c, B, s));
     RUN(uw_decode_greedy(c, prompt_ids, ld_prompt, prompt_len_host, B, max_tokens, eot, sot, ts_begin, ts_end, new_tokens, n_new,
                          text_ids, n_text, stream));

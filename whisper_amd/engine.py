@@ -85,7 +85,11 @@ class Engine:
     def profile_end(self) -> Dict[str, float]:
         total, timed, windows, ms = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
         L.check(self.lib.uw_profile_end(self.ctx, C.byref(total), C.byref(timed), C.byref(windows), C.byref(ms)))
-        return {"launches": total.value, "timed": timed.value, "windows": windows.value, "timed_ms": ms.value}
+        out = {"launches": total.value, "timed": timed.value, "windows": windows.value, "timed_ms": ms.value}
+        for kind, name in ((1, "self_decode"), (2, "encoder"), (3, "dtw")):
+            L.check(self.lib.uw_profile_span(self.ctx, kind, C.byref(total), C.byref(timed), C.byref(ms)))
+            out[name] = {"launches": total.value, "timed": timed.value, "timed_ms": ms.value}
+        return out
 
     # ---- stages ---------------------------------------------------------------------------------
     def mel(self, audio: torch.Tensor, n_samples: torch.Tensor) -> torch.Tensor:

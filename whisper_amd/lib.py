@@ -57,6 +57,7 @@ SIGNATURES = {
                                         C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     "uw_profile_begin": (C.c_int, [_vp, C.c_int]),
     "uw_profile_end": (C.c_int, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_double)]),
+    "uw_profile_span": (C.c_int, [_vp, C.c_int, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(C.c_double)]),
 }
 
 _lib: Optional[C.CDLL] = None
