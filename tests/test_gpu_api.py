@@ -83,6 +83,41 @@ def test_sessions_reproduce_reference_loops(sessions):
         assert got.shape == (1, dims.n_heads, len(cur), 1500) and np.abs(got - ref).max() < 1e-6
 
 
+def test_merged_decoder_surface_runs_the_reference_dummy_cache_branch(sessions):
+    """decoder_model_merged.onnx is the file the reference prefers (download.py:259).  Its session declares the cache
+    inputs; the reference then feeds EMPTY caches and use_cache_branch=False on every call (core.py:185-192, 840-871,
+    943-946; align.py:611-614).  Driven that way the merged surface gives what the plain one gives."""
+    import re as _re
+    from whisper_amd.session import DecoderSession
+    enc, dec = sessions
+    dims = dims_for("micro")
+    merged = DecoderSession(enc.engine, merged=True)
+    names = [i.name for i in merged.get_inputs()]
+    kv_names = [n for n in names if n.startswith("past_key_values")]
+    assert "use_cache_branch" in names and len(kv_names) == 4 * dims.dec_layers
+    n_layers = 1 + max(int(_re.search(r"past_key_values\.(\d+)\.", n).group(1)) for n in kv_names)      # core.py:843-848
+    assert n_layers == dims.dec_layers
+    hidden = enc.run(None, {enc.get_inputs()[0].name: O.log_mel_segment(synth_audio(4), 80).astype(np.float32)})[0]
+    past = {n: np.empty((1, dims.d_model // 64, 0, 64), dtype=np.float32) for n in kv_names}               # core.py:859-862
+    cur = [824, 825, 826, 924, 7]
+    attn_names = [o.name for o in merged.get_outputs() if "cross_attentions" in o.name]
+    for _ in range(3):
+        feeds = {"input_ids": np.array([cur], dtype=np.int64), "encoder_hidden_states": hidden.astype(np.float32)}
+        plain = dec.run(["logits"], feeds)[0]
+        feeds.update(past)
+        feeds["use_cache_branch"] = np.array([False], dtype=bool)
+        got = merged.run(["logits"], feeds)[0]
+        assert np.array_equal(got, plain)
+        for a, b in zip(merged.run(attn_names, feeds), dec.run(attn_names, {k: feeds[k] for k in ("input_ids", "encoder_hidden_states")})):
+            assert np.array_equal(a, b)
+        cur.append(int(np.argmax(got[0, -1])))
+    with pytest.raises(Exception, match="are missing from input feed"):
+        merged.run(["logits"], {"input_ids": np.array([cur], dtype=np.int64), "encoder_hidden_states": hidden})
+    feeds["use_cache_branch"] = np.array([True], dtype=bool)
+    with pytest.raises(ValueError, match="use_cache_branch"):
+        merged.run(["logits"], feeds)
+
+
 def _engine(max_batch=4):
     from whisper_amd.engine import Engine
     dims = dims_for("micro")
@@ -132,19 +167,21 @@ def test_whisperer_on_gpu_reproduces_reference_core_golden():
     import json
     import os
     from tests.helpers import WordTokenizer
-    from tests.test_reference_e2e import CASES, GOLD
+    from tests.test_reference_e2e import CASES, GOLD, heads_for
     from whisper_amd import engine as E
-    from whisper_amd.config import alignment_heads, alignment_heads_key
     gold = json.load(open(GOLD))
     dims = dims_for(gold["model"])
     sd = synthetic_state_dict(dims, seed=gold["weights"]["seed"], std=gold["weights"]["std"])
-    heads = alignment_heads(alignment_heads_key(gold["model"], dims.d_model, "en"), dims.dec_layers, dims.n_heads)
-    eng = E.Engine(dims, sd, dtype="f32", max_batch=2, align_heads=heads)
+    engines = {}
     try:
         for name in CASES:
             kw = dict(CASES[name])
             audio = synth_audio(kw.pop("audio_seed"), kw.pop("n_samples"))
-            res = whisperer(model=gold["model"], audio=audio, language="en", tokenizer=WordTokenizer(), engine=eng, **kw)
+            model = kw.pop("model", gold["model"])
+            heads = tuple(heads_for(model, dims))      # the mask the reference resolves for this model string ([] on a mismatch)
+            if heads not in engines:
+                engines[heads] = E.Engine(dims, sd, dtype="f32", max_batch=2, align_heads=list(heads))
+            res = whisperer(model=model, audio=audio, language="en", tokenizer=WordTokenizer(), engine=engines[heads], **kw)
             ref = gold["cases"][name]
             if kw.get("stream"):      # generator mode (core.py:238-536): the yielded pieces, in order
                 assert list(res) == ref["pieces"], name
@@ -156,7 +193,8 @@ def test_whisperer_on_gpu_reproduces_reference_core_golden():
                      for g, e in zip(res["words"], ref["words"]) if e["start"] is not None]
             assert all(close), (name, sum(close), len(close))
     finally:
-        eng.close()
+        for eng in engines.values():
+            eng.close()
 
 
 def test_context_without_alignment_heads_transcribes_untimed():

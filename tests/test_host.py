@@ -59,3 +59,41 @@ def test_system_icu_word_breaker():
     assert spans[0][0] == 0 and spans[-1][1] == len(t) and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
     u = "a 😀 b"                                # one astral character = two UTF-16 units
     assert A._icu_c_word_spans(u, "en")[-1][1] == len(u) + 1
+
+
+def test_merged_decoder_session_surface_and_cross_kv_key():
+    """The merged-decoder surface (what core.py:185-192 probes) and the cross-K/V cache key, on a stand-in engine."""
+    import torch
+    from whisper_amd.session import DecoderSession
+
+    class Eng:
+        dims = CFG.dims_for("micro")
+        device = torch.device("cpu")
+        projected = 0
+
+        def cross_kv(self, B, enc):
+            self.projected += 1
+
+    eng = Eng()
+    plain, merged = DecoderSession(eng), DecoderSession(eng, merged=True)
+    assert [i.name for i in plain.get_inputs()] == ["input_ids", "encoder_hidden_states"]
+    names = [i.name for i in merged.get_inputs()]
+    assert names[:2] == ["input_ids", "encoder_hidden_states"] and names[-1] == "use_cache_branch"
+    assert names[2:6] == [f"past_key_values.0.{s}.{kv}" for s in ("decoder", "encoder") for kv in ("key", "value")]
+    assert len(names) == 3 + 4 * eng.dims.dec_layers
+    with pytest.raises(ValueError, match="are missing from input feed"):
+        merged.run(["logits"], {"input_ids": np.zeros((1, 2), np.int64), "encoder_hidden_states": np.zeros((1, 1500, 128), np.float32)})
+    feeds = {n: np.empty((1, 2, 0, 64), np.float32) for n in names[2:-1]}
+    feeds.update({"input_ids": np.zeros((1, 2), np.int64), "encoder_hidden_states": np.zeros((1, 1500, 128), np.float32),
+                  "use_cache_branch": np.array([False])})
+    bad = dict(feeds)
+    bad[names[2]] = np.zeros((1, 2, 3, 64), np.float32)
+    with pytest.raises(ValueError, match="empty cache"):
+        merged.run(["logits"], bad)
+    # the reference hands over a fresh astype() copy of the same states on every step: one projection per content
+    enc = np.random.default_rng(0).standard_normal((1, 1500, 128)).astype(np.float32)
+    for _ in range(3):
+        plain._ensure_cross_kv(enc.astype(np.float32).copy())
+    assert eng.projected == 1
+    plain._ensure_cross_kv(enc * 1.0001)         # another window's states differ everywhere, so also in the sample
+    assert eng.projected == 2

@@ -24,7 +24,19 @@ CASES = {
                              transcript=" ".join(f"w{300 + i}" for i in range(26)) + ", w77."),
     "stream_hyphen": dict(audio_seed=25, n_samples=16000 * 38, max_tokens=20, delimiter=" -", stream=True),
     "stream_plain": dict(audio_seed=26, n_samples=16000 * 33, max_tokens=16, stream=True),
+    # diarization: 60 s chunks for a "medium" model string, offset follows the last word (core.py:738-746,775-786,1156-1169)
+    "speaker_diarization": dict(model="whisper-medium_timestamped", audio_seed=27, n_samples=16000 * 100, max_tokens=26,
+                                delimiter=" [SPEAKER 1]"),
+    # user prompt + delimiter with prefix and audio-context carry-over (core.py:874-922,1058-1142)
+    "prompt_delimiter_context": dict(audio_seed=28, n_samples=16000 * 70, max_tokens=40, prompt="w700, w701.", delimiter=" >"),
+    # model string that is a head-table key of another size: no alignment, untimed words (align.py:81-84,595-597)
+    "mask_mismatch": dict(model="medium", audio_seed=29, n_samples=16000 * 35, max_tokens=20),
 }
+
+
+def heads_for(case_model, dims):
+    """The alignment heads the reference resolves for this model string on these shapes (align.py:572-597)."""
+    return alignment_heads(alignment_heads_key(case_model, dims.d_model, "en"), dims.dec_layers, dims.n_heads) or []
 
 
 @pytest.fixture(scope="module")
@@ -32,18 +44,25 @@ def engine():
     gold = json.load(open(GOLD))
     dims = dims_for(gold["model"])
     sd = synthetic_state_dict(dims, seed=gold["weights"]["seed"], std=gold["weights"]["std"])
-    heads = alignment_heads(alignment_heads_key(gold["model"], dims.d_model, "en"), dims.dec_layers, dims.n_heads)
-    return gold, OracleEngine(dims, sd, heads, max_batch=2)
+    engines = {}
+
+    def get(case_model):
+        key = tuple(heads_for(case_model, dims))
+        if key not in engines:
+            engines[key] = OracleEngine(dims, sd, list(key), max_batch=2)
+        return engines[key]
+    return gold, get
 
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_whisperer_matches_reference_core(engine, name):
     if not A._system_icu():
         pytest.skip("the golden was made with ICU word breaks; no system ICU here")
-    gold, eng = engine
+    gold, get_engine = engine
     kw = dict(CASES[name])
     audio = synth_audio(kw.pop("audio_seed"), kw.pop("n_samples"))
-    res = whisperer(model=gold["model"], audio=audio, language="en", tokenizer=WordTokenizer(), engine=eng, **kw)
+    model = kw.pop("model", gold["model"])
+    res = whisperer(model=model, audio=audio, language="en", tokenizer=WordTokenizer(), engine=get_engine(model), **kw)
     ref = gold["cases"][name]
     if kw.get("stream"):
         assert list(res) == ref["pieces"]

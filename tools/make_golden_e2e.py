@@ -152,6 +152,17 @@ def cases():
                                  transcript=" ".join(f"w{300 + i}" for i in range(26)) + ", w77."),
         "stream_hyphen": dict(audio_seed=25, n_samples=16000 * 38, max_tokens=20, delimiter=" -", stream=True),
         "stream_plain": dict(audio_seed=26, n_samples=16000 * 33, max_tokens=16, stream=True),
+        # diarization mode (core.py:738-746, 775-786, 1156-1169): a model string containing "medium" selects 60 s chunks
+        # (only their first 30 s are encoded) and the next chunk starts at the last word's end when that advances > 10 s;
+        # the string is no key of the alignment-head table, so the mask is still picked by width (tiny.en)
+        "speaker_diarization": dict(model="whisper-medium_timestamped", audio_seed=27, n_samples=16000 * 100, max_tokens=26,
+                                    delimiter=" [SPEAKER 1]"),
+        # user prompt + segmentation delimiter: prompt ids in front of every chunk, prefix and audio context carried over
+        # (core.py:874-922, 1058-1142)
+        "prompt_delimiter_context": dict(audio_seed=28, n_samples=16000 * 70, max_tokens=40, prompt="w700, w701.", delimiter=" >"),
+        # a model string that IS a key of the alignment-head table but whose mask has another size than layers x heads:
+        # no alignment at all, words come back untimed (align.py:81-84, 595-597; core.py:1041-1052)
+        "mask_mismatch": dict(model="medium", audio_seed=29, n_samples=16000 * 35, max_tokens=20),
     }
 
 
@@ -168,7 +179,7 @@ def main():
     for name, kw in cases().items():
         kw = dict(kw)
         audio = synth_audio(kw.pop("audio_seed"), kw.pop("n_samples"))
-        res = urro_whisper.whisperer(model=MODEL, audio=audio, language="en", onnx_encoder=enc_p, onnx_decoder=dec_p,
+        res = urro_whisper.whisperer(model=kw.pop("model", MODEL), audio=audio, language="en", onnx_encoder=enc_p, onnx_decoder=dec_p,
                                      onnx_providers=["CPUExecutionProvider"], **kw)
         if kw.get("stream"):
             pieces = list(res)

@@ -74,7 +74,9 @@ def load_onnx_models(encoder_path, decoder_path, onnx_providers=None, verbose=Fa
     dims = dims_for(name)
     heads = alignment_heads(alignment_heads_key(name, dims.d_model, language), dims.dec_layers, dims.n_heads) or []
     eng = Engine(dims, sd, dtype=dtype, max_batch=max_batch, align_heads=heads)
-    enc, dec = EncoderSession(eng), DecoderSession(eng)
+    # decoder_model_merged.onnx (what the reference prefers, download.py:259) declares the cache inputs; mirror that
+    merged = isinstance(decoder_path, str) and "merged" in os.path.basename(decoder_path)
+    enc, dec = EncoderSession(eng), DecoderSession(eng, merged=merged)
     logger.info(f"models loaded using {enc.get_providers()} for encoder and {dec.get_providers()} for decoder")
     return enc, dec
 
