@@ -129,54 +129,72 @@ __global__ __launch_bounds__(64 * DTW_MAX_BANDS) void dtw_kernel(const double* _
         uint32_t dword = 0;
         int known = 0;  // columns of the band above known to be published
         const int steps = M + 63;
-        for (int t = 0; t < steps; ++t) {
-            const int j = t - lane;
-            // the wave needs column min(t, M-1) of the band above for lane 0
-            if (band > 0) {
-                const int need = min(t, M - 1) + 1;
-                if (known < need) {
-                    int spins = 0;
-                    do {
-                        known = __hip_atomic_load(&progress[band - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (known >= need) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    } while (++spins < (1 << 24));
-                    if (known < need) s_len[1] = 1;  // never expected: the band above always advances
+        // The cost value of a step is an 8-byte read from this lane's own row, 64 different cache lines per wave
+        // instruction: far too slow to sit on the recurrence's dependency chain.  Each lane keeps the values of its next
+        // PF steps in registers, loaded PF steps ahead (out-of-range steps read a valid cell and ignore it).
+        constexpr int PF = 8;
+        double cbuf[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) cbuf[u] = crow[min(max(u - lane, 0), M - 1)];
+        // the step count is rounded up to a multiple of PF: in the extra steps every lane is past its last column
+        for (int t0 = 0; t0 < steps; t0 += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int t = t0 + u;
+                const int j = t - lane;
+                // the wave needs column min(t, M-1) of the band above for lane 0
+                if (band > 0) {
+                    const int need = min(t, M - 1) + 1;
+                    if (known < need) {
+                        int spins = 0;
+                        do {
+                            // progress counter and edge row both live in LDS, and a wave's LDS operations execute in
+                            // order: a relaxed load (no vector-memory wait, which would drain the prefetched cost
+                            // values) followed by the edge read is enough
+                            known = __hip_atomic_load(&progress[band - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            asm volatile("" ::: "memory");
+                            if (known >= need) break;
+                            __builtin_amdgcn_s_sleep(1);
+                        } while (++spins < (1 << 24));
+                        if (known < need) s_len[1] = 1;  // never expected: the band above always advances
+                    }
                 }
-            }
-            // D[i-1][j] : neighbour lane's value from the previous step, or the band edge for lane 0
-            double up = __shfl_up(mine_prev, 1, 64);
-            if (lane == 0 && band > 0 && j >= 0 && j < M) up = up_edge[j];
-            const bool active = row_ok && j >= 0 && j < M;
-            double mine = mine_prev;
-            if (active) {
-                const double c = crow[j];
-                double best = INFINITY;
-                uint32_t arg = 0;
-                if (i == 0 && j == 0) {
-                    best = c;
-                } else {
-                    if (i > 0 && j > 0) { const double v = up_prev + c; if (v < best) { best = v; arg = 1; } }
-                    if (j > 0)          { const double v = left + c;    if (v < best) { best = v; arg = 2; } }
-                    if (i > 0)          { const double v = up + c;      if (v < best) { best = v; arg = 3; } }
+                // D[i-1][j] : neighbour lane's value from the previous step, or the band edge for lane 0
+                double up = __shfl_up(mine_prev, 1, 64);
+                if (lane == 0 && band > 0 && j >= 0 && j < M) up = up_edge[j];
+                const bool active = row_ok && j >= 0 && j < M;
+                const double c = cbuf[u];
+                cbuf[u] = crow[min(max(j + PF, 0), M - 1)];
+                double mine = mine_prev;
+                if (active) {
+                    double best = INFINITY;
+                    uint32_t arg = 0;
+                    if (i == 0 && j == 0) {
+                        best = c;
+                    } else {
+                        if (i > 0 && j > 0) { const double v = up_prev + c; if (v < best) { best = v; arg = 1; } }
+                        if (j > 0)          { const double v = left + c;    if (v < best) { best = v; arg = 2; } }
+                        if (i > 0)          { const double v = up + c;      if (v < best) { best = v; arg = 3; } }
+                    }
+                    mine = best;
+                    left = best;
+                    dword |= arg << ((j & 15) * 2);
+                    if ((j & 15) == 15 || j == M - 1) {
+                        dir[(size_t)i * dir_words + (j >> 4)] = dword;
+                        dword = 0;
+                    }
+                    if (writes_edge) my_edge[j] = best;
                 }
-                mine = best;
-                left = best;
-                dword |= arg << ((j & 15) * 2);
-                if ((j & 15) == 15 || j == M - 1) {
-                    dir[(size_t)i * dir_words + (j >> 4)] = dword;
-                    dword = 0;
-                }
-                if (writes_edge) my_edge[j] = best;
-            }
-            up_prev = up;   // becomes D[i-1][j-1] for the next step
-            mine_prev = mine;
-            if (band + 1 < n_bands) {
-                // lane 63 finished column t-63; publish in batches
-                const int done = t - 63 + 1;
-                if (done > 0 && ((done % DTW_PUBLISH) == 0 || done == M)) {
-                    if (lane == 63)
-                        __hip_atomic_store(&progress[band], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                up_prev = up;   // becomes D[i-1][j-1] for the next step
+                mine_prev = mine;
+                if (band + 1 < n_bands) {
+                    // lane 63 finished column t-63; publish in batches
+                    const int done = t - 63 + 1;
+                    if (done > 0 && done <= M && ((done % DTW_PUBLISH) == 0 || done == M)) {
+                        asm volatile("" ::: "memory");   // the edge writes above are issued before the counter (same wave, LDS order)
+                        if (lane == 63)
+                            __hip_atomic_store(&progress[band], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
         }

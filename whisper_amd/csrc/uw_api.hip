@@ -615,17 +615,19 @@ __global__ void embed_step_kernel(float* __restrict__ x, const float* __restrict
     for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) *(f32x4*)(x + x_elem_offset<T>(b, i * 4, d)) = e[i] + pe[i];
 }
 
-int decoder_step_chunk(uw_ctx* c, int b0, int B, hipStream_t s);
+int decoder_step_chunk(uw_ctx* c, int b0, int B, bool embed, hipStream_t s);
 // one KV-cached decoder step for the token at st_pos[b] of windows [b0, b0 + B) -> their rows of c->logits.
 // The step's products take at most 128 rows per launch: larger batches go through in chunks of 128 windows.
-int decoder_step(uw_ctx* c, int b0, int B, hipStream_t s)
+// embed: build the residual-stream rows from st_tokens / st_pos first (the greedy loop's later steps get them from
+// the previous step's uw_greedy_next instead)
+int decoder_step(uw_ctx* c, int b0, int B, bool embed, hipStream_t s)
 {
-    for (int off = 0; off < B; off += 128) RUN(decoder_step_chunk(c, b0 + off, std::min(128, B - off), s));
+    for (int off = 0; off < B; off += 128) RUN(decoder_step_chunk(c, b0 + off, std::min(128, B - off), embed, s));
     return UW_OK;
 }
 
 // Every buffer is indexed by window, so disjoint window ranges (starting on multiples of 16) are independent.
-int decoder_step_chunk(uw_ctx* c, int b0, int B, hipStream_t s)
+int decoder_step_chunk(uw_ctx* c, int b0, int B, bool embed, hipStream_t s)
 {
     const int d = c->d, S = c->S, H = c->H, Tm = c->Tm;
     const size_t es = c->es;
@@ -640,11 +642,13 @@ int decoder_step_chunk(uw_ctx* c, int b0, int B, hipStream_t s)
     float* logits = c->logits + (long)b0 * c->logits_ld;
     const int32_t* pos = c->st_pos + b0;
     const int32_t* active = c->st_active + b0;
-    if (c->dt == UW_F32)
-        hipLaunchKernelGGL(embed_step_kernel<float>, dim3(B), dim3(256), 0, s, x, c->tok_emb32, c->dec_pos, c->st_tokens + (long)b0 * Tm, Tm, pos, d, c->V, Tm);
-    else
-        hipLaunchKernelGGL(embed_step_kernel<bf16_t>, dim3(B), dim3(256), 0, s, x, c->tok_emb32, c->dec_pos, c->st_tokens + (long)b0 * Tm, Tm, pos, d, c->V, Tm);
-    UW_LAUNCH_CHECK();
+    if (embed) {
+        if (c->dt == UW_F32)
+            hipLaunchKernelGGL(embed_step_kernel<float>, dim3(B), dim3(256), 0, s, x, c->tok_emb32, c->dec_pos, c->st_tokens + (long)b0 * Tm, Tm, pos, d, c->V, Tm);
+        else
+            hipLaunchKernelGGL(embed_step_kernel<bf16_t>, dim3(B), dim3(256), 0, s, x, c->tok_emb32, c->dec_pos, c->st_tokens + (long)b0 * Tm, Tm, pos, d, c->V, Tm);
+        UW_LAUNCH_CHECK();
+    }
     for (size_t li = 0; li < c->dec.size(); ++li) {
         auto& l = c->dec[li];
         char* skv = (char*)c->self_kv + li * self_kv_layer_bytes(c) + (size_t)b0 * Tm * 2 * d * es;
@@ -968,7 +972,7 @@ int uw_decode_step(uw_ctx* c, const int32_t* ids, const int32_t* pos, int B, flo
     hipLaunchKernelGGL(step_state_kernel, dim3((B + 63) / 64), dim3(64), 0, s, c->st_tokens, c->Tm, c->st_pos, c->st_active, c->st_n_text,
                        ids, pos, B, c->Tm);
     UW_LAUNCH_CHECK();
-    RUN(decoder_step(c, 0, B, s));
+    RUN(decoder_step(c, 0, B, true, s));
     UW_HIP_CHECK(hipMemcpy2DAsync(logits, (size_t)c->V * 4, c->logits, (size_t)c->logits_ld * 4, (size_t)c->V * 4, B,
                                   hipMemcpyDeviceToDevice, s));
     return UW_OK;
@@ -1026,9 +1030,9 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
                 sk.tokens += (long)b0 * st.ld_tok; sk.text_ids += (long)b0 * st.ld_tok;
                 sk.pos += b0; sk.n_new += b0; sk.n_text += b0; sk.active += b0; sk.dirty_from += b0; sk.max_new += b0;
                 sk.n_active = c->st_n_active + k;
-                RUN(decoder_step(c, b0, Bn, ss[k]));
-                RUN(uw_argmax_rows(c->logits + (long)b0 * c->logits_ld, c->logits_ld, Bn, c->V, c->st_next + b0, ss[k]));
-                RUN(uw_greedy_advance(sk, c->st_next + b0, Bn, eot, sot, ts_begin, ts_end, ss[k]));
+                RUN(decoder_step(c, b0, Bn, step == 0, ss[k]));
+                RUN(uw_greedy_next(c->dt, sk, c->logits + (long)b0 * c->logits_ld, c->logits_ld, Bn, c->V, eot, sot, ts_begin, ts_end,
+                                   c->d_x + (long)b0 * c->d, c->tok_emb32, c->dec_pos, c->d, ss[k]));
                 if ((step & 7) == 7 && step + 1 < max_steps) {
                     // non-blocking look at the counter copied 8 steps ago, then queue the next copy
                     if (step >= 15 && hipEventQuery(c->sub_event[k]) == hipSuccess && h_active[k] <= 0) sub_done[k] = true;

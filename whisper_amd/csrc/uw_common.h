@@ -181,6 +181,44 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// First index of the maximum of row[0..V) (numpy argmax tie rule; NaN never wins, inputs are finite logits), computed by
+// a 1024-thread workgroup: 16-byte loads, four independent loads in flight per thread.  sv / si: 16-entry LDS scratch.
+// The result is valid in thread 0 (after the internal barrier); row must be 16-byte aligned for the vector path.
+__device__ __forceinline__ int block_argmax_1024(const float* __restrict__ row, int V, float* sv, int* si)
+{
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    auto take = [&](float v, int i) { if (v > best || (v == best && i < arg)) { best = v; arg = i; } };
+    const bool vec = (((uintptr_t)row & 15) == 0);
+    const int V4 = vec ? (V >> 2) : 0;
+    for (int i0 = threadIdx.x; i0 < V4; i0 += 4096) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 1024;
+            v[u] = (i < V4) ? ((const f32x4*)row)[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) take(v[u][k], (i0 + u * 1024) * 4 + k);
+    }
+    for (int i = V4 * 4 + threadIdx.x; i < V; i += 1024) take(row[i], i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(arg, o, 64);
+        if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = arg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < arg)) { best = sv[w]; arg = si[w]; }
+    }
+    return (arg == 0x7fffffff) ? 0 : arg;
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Function attributes (the dynamic LDS limit) are kept per device: one flag per device ordinal, so a process that

@@ -430,36 +430,54 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
 }
 
 // ------------------------------------------------------------------------------------------------
-// one thread per window: urro_whisper/core.py:959-968 (stop on eot without appending, budget) and :991 (text filter)
-__global__ void greedy_advance_kernel(GreedyState st, const int32_t* __restrict__ next_tok, int B, int eot, int sot,
-                                      int ts_begin, int ts_end)
+// End of a greedy step for one window per workgroup: argmax of its logits (np.argmax, first index on ties),
+// urro_whisper/core.py:959-968 (stop on eot without appending, budget) and :991 (text filter), then -- if the window
+// goes on -- the embedding of the token just chosen, written as the next step's residual-stream row.
+template <typename T>
+__global__ __launch_bounds__(1024) void greedy_next_kernel(GreedyState st, const float* __restrict__ logits, long ld, int V, int eot,
+                                                           int sot, int ts_begin, int ts_end, float* __restrict__ x,
+                                                           const float* __restrict__ tok_emb, const float* __restrict__ pos_emb, int d)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B || !st.active[b]) return;
-    const int tok = next_tok[b];
-    bool alive = true;
-    if (tok == eot) {
-        alive = false;
-    } else {
-        const int idx = st.pos[b] + 1;   // pos = index of the token that produced these logits
-        st.tokens[(long)b * st.ld_tok + idx] = tok;
-        st.pos[b] = idx;
-        const int nn = st.n_new[b] + 1;
-        st.n_new[b] = nn;
-        const bool is_text = tok < sot && !(tok >= ts_begin && tok <= ts_end);
-        if (is_text) {
-            const int nt = st.n_text[b];
-            st.text_ids[(long)b * st.ld_tok + nt] = tok;
-            st.n_text[b] = nt + 1;
-        } else if (st.dirty_from[b] < 0) {
-            st.dirty_from[b] = st.n_text[b];  // rows captured from here on see a context the reference never builds
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ int s_next[2];
+    const int b = blockIdx.x;
+    if (!st.active[b]) return;
+    const int tok = block_argmax_1024(logits + (long)b * ld, V, sv, si);
+    if (threadIdx.x == 0) {
+        bool alive = true;
+        int idx = -1;
+        if (tok == eot) {
+            alive = false;
+        } else {
+            idx = st.pos[b] + 1;   // pos = index of the token that produced these logits
+            st.tokens[(long)b * st.ld_tok + idx] = tok;
+            st.pos[b] = idx;
+            const int nn = st.n_new[b] + 1;
+            st.n_new[b] = nn;
+            const bool is_text = tok < sot && !(tok >= ts_begin && tok <= ts_end);
+            if (is_text) {
+                const int nt = st.n_text[b];
+                st.text_ids[(long)b * st.ld_tok + nt] = tok;
+                st.n_text[b] = nt + 1;
+            } else if (st.dirty_from[b] < 0) {
+                st.dirty_from[b] = st.n_text[b];  // rows captured from here on see a context the reference never builds
+            }
+            if (nn >= st.max_new[b]) alive = false;
         }
-        if (nn >= st.max_new[b]) alive = false;
+        if (!alive) {
+            st.active[b] = 0;
+            atomicSub(st.n_active, 1);
+        }
+        s_next[0] = alive ? idx : -1;
+        s_next[1] = tok;
     }
-    if (!alive) {
-        st.active[b] = 0;
-        atomicSub(st.n_active, 1);
-    }
+    __syncthreads();
+    const int pos = s_next[0];
+    if (pos < 0) return;
+    const f32x4* e = (const f32x4*)(tok_emb + (long)min(max(s_next[1], 0), V - 1) * d);
+    const f32x4* pe = (const f32x4*)(pos_emb + (long)pos * d);
+    for (int i = threadIdx.x; i < (d >> 2); i += 1024) *(f32x4*)(x + x_elem_offset<T>(b, i * 4, d)) = e[i] + pe[i];
 }
 
 }  // namespace
@@ -510,10 +528,14 @@ int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s)
     return UW_OK;
 }
 
-int uw_greedy_advance(const GreedyState& st, const int32_t* next_tok, int B, int eot, int sot, int ts_begin, int ts_end,
-                      hipStream_t s)
+int uw_greedy_next(int dtype, const GreedyState& st, const float* logits, long ld, int B, int V, int eot, int sot, int ts_begin,
+                   int ts_end, float* x, const float* tok_emb, const float* pos_emb, int d, hipStream_t s)
 {
-    hipLaunchKernelGGL(greedy_advance_kernel, dim3((B + 63) / 64), dim3(64), 0, s, st, next_tok, B, eot, sot, ts_begin, ts_end);
+    UW_REQUIRE(logits && x && tok_emb && pos_emb && B > 0 && d % 4 == 0, "greedy_next: bad arguments");
+    if (dtype == UW_F32)
+        hipLaunchKernelGGL(greedy_next_kernel<float>, dim3(B), dim3(1024), 0, s, st, logits, ld, V, eot, sot, ts_begin, ts_end, x, tok_emb, pos_emb, d);
+    else
+        hipLaunchKernelGGL(greedy_next_kernel<bf16_t>, dim3(B), dim3(1024), 0, s, st, logits, ld, V, eot, sot, ts_begin, ts_end, x, tok_emb, pos_emb, d);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }

@@ -166,45 +166,14 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(float* __restrict__ x
     for (int c = threadIdx.x; c < (d >> 2); c += 256) o[c] = e[c] + p[c];
 }
 
-// first index of the maximum (numpy argmax tie rule); NaN never wins here, inputs are finite logits.
-// One 1024-thread workgroup per row, 16-byte loads, four independent loads in flight per thread.
+// first index of the maximum (numpy argmax tie rule); one 1024-thread workgroup per row
 __global__ __launch_bounds__(1024) void argmax_rows_kernel(const float* __restrict__ logits, long ld, int V,
                                                            int32_t* __restrict__ out)
 {
     __shared__ float sv[16];
     __shared__ int si[16];
-    const float* row = logits + (long)blockIdx.x * ld;
-    float best = -INFINITY;
-    int arg = 0x7fffffff;
-    auto take = [&](float v, int i) { if (v > best || (v == best && i < arg)) { best = v; arg = i; } };
-    const bool vec = ((ld & 3) == 0) && (((uintptr_t)logits & 15) == 0);
-    const int V4 = vec ? (V >> 2) : 0;
-    for (int i0 = threadIdx.x; i0 < V4; i0 += 4096) {
-        f32x4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 1024;
-            v[u] = (i < V4) ? ((const f32x4*)row)[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) take(v[u][k], (i0 + u * 1024) * 4 + k);
-    }
-    for (int i = V4 * 4 + threadIdx.x; i < V; i += 1024) take(row[i], i);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(arg, o, 64);
-        if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }
-    }
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = arg; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w)
-            if (sv[w] > best || (sv[w] == best && si[w] < arg)) { best = sv[w]; arg = si[w]; }
-        out[blockIdx.x] = (arg == 0x7fffffff) ? 0 : arg;
-    }
+    const int arg = block_argmax_1024(logits + (long)blockIdx.x * ld, V, sv, si);
+    if (threadIdx.x == 0) out[blockIdx.x] = arg;
 }
 
 inline int stream_grid(long n, int block) { return (int)(n / block + 1 < 4096 ? n / block + 1 : 4096); }

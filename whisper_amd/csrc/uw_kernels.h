@@ -154,9 +154,10 @@ struct GreedyState {
     int32_t* n_active = nullptr;   // [1] windows still decoding
     int32_t* text_ids = nullptr;   // [B][ld_tok] generated text tokens
 };
-// consumes argmax results: appends, stops on eot / budget, classifies text tokens, advances pos
-int uw_greedy_advance(const GreedyState& st, const int32_t* next_tok, int B, int eot, int sot, int ts_begin, int ts_end,
-                      hipStream_t s);
+// end of a greedy step: argmax of logits[b][0..V) per window, append / stop on eot / budget, classify text tokens,
+// advance pos, and write the chosen token's embedding as row b of the next step's residual stream x (x layout)
+int uw_greedy_next(int dtype, const GreedyState& st, const float* logits, long ld, int B, int V, int eot, int sot, int ts_begin,
+                   int ts_end, float* x, const float* tok_emb, const float* pos_emb, int d, hipStream_t s);
 
 // ---- uw_mel.hip -------------------------------------------------------------------------------
 struct MelTables;  // device tables owned by the context
