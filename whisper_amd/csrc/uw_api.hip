@@ -82,6 +82,7 @@ struct uw_ctx {
             *st_qfirst = nullptr, *st_qcount = nullptr, *st_zero = nullptr, *st_ids = nullptr;
     int32_t* host_pin = nullptr;   // pinned scratch for small read-backs
     int cross_batch = 0;           // windows covered by the current cross K/V
+    int step_rows = 0;             // upper bound of (position + 1) of the next decode step over its windows (0: unknown)
     bool enc_valid = false;
     // optional timing of the cross-attention decode kernel (the dominant HBM stream)
     bool prof_on = false;
@@ -656,7 +657,7 @@ int decoder_step_chunk(uw_ctx* c, int b0, int B, bool embed, hipStream_t s)
         RUN(gemm_step_ln(c, x, l.self.wqkv_p, l.self.ln_g, l.self.bln, l.self.wsum, qkv, 3 * d, B, 3 * d, d, 0, false, s));
         SelfDecodeParams sp;
         sp.qkv = qkv; sp.kcache = skv; sp.vcache = skv + (size_t)Tm * d * es; sp.out = att; sp.out_lo = att_lo;
-        sp.pos = pos; sp.active = active; sp.ld_cache = 64; sp.cache_sB = (long)Tm * 2 * d; sp.cache_sH = (long)Tm * 64; sp.out_packed = 1; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm;
+        sp.pos = pos; sp.active = active; sp.ld_cache = 64; sp.cache_sB = (long)Tm * 2 * d; sp.cache_sH = (long)Tm * 64; sp.out_packed = 1; sp.B = B; sp.H = H; sp.d = d; sp.n_ctx = Tm; sp.max_rows = c->step_rows;
         const int self_slot = span_begin(c, 1, 8, s);
         RUN(uw_self_attn_decode(c->dt, sp, s));
         span_end(c, 1, self_slot, s);
@@ -972,6 +973,7 @@ int uw_decode_step(uw_ctx* c, const int32_t* ids, const int32_t* pos, int B, flo
     hipLaunchKernelGGL(step_state_kernel, dim3((B + 63) / 64), dim3(64), 0, s, c->st_tokens, c->Tm, c->st_pos, c->st_active, c->st_n_text,
                        ids, pos, B, c->Tm);
     UW_LAUNCH_CHECK();
+    c->step_rows = 0;   // positions are device data here
     RUN(decoder_step(c, 0, B, true, s));
     UW_HIP_CHECK(hipMemcpy2DAsync(logits, (size_t)c->V * 4, c->logits, (size_t)c->logits_ld * 4, (size_t)c->V * 4, B,
                                   hipMemcpyDeviceToDevice, s));
@@ -1030,6 +1032,7 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
                 sk.tokens += (long)b0 * st.ld_tok; sk.text_ids += (long)b0 * st.ld_tok;
                 sk.pos += b0; sk.n_new += b0; sk.n_text += b0; sk.active += b0; sk.dirty_from += b0; sk.max_new += b0;
                 sk.n_active = c->st_n_active + k;
+                c->step_rows = std::min(c->Tm, Pmax + step);   // the longest prompt's position + 1 at this step
                 RUN(decoder_step(c, b0, Bn, step == 0, ss[k]));
                 RUN(uw_greedy_next(c->dt, sk, c->logits + (long)b0 * c->logits_ld, c->logits_ld, Bn, c->V, eot, sot, ts_begin, ts_end,
                                    c->d_x + (long)b0 * c->d, c->tok_emb32, c->dec_pos, c->d, ss[k]));

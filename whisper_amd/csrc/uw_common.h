@@ -182,7 +182,7 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 // First index of the maximum of row[0..V) (numpy argmax tie rule; NaN never wins, inputs are finite logits), computed by
-// a 1024-thread workgroup: 16-byte loads, four independent loads in flight per thread.  sv / si: 16-entry LDS scratch.
+// a 1024-thread workgroup: 16-byte loads, eight independent loads in flight per thread.  sv / si: 16-entry LDS scratch.
 // The result is valid in thread 0 (after the internal barrier); row must be 16-byte aligned for the vector path.
 __device__ __forceinline__ int block_argmax_1024(const float* __restrict__ row, int V, float* sv, int* si)
 {
@@ -191,15 +191,15 @@ __device__ __forceinline__ int block_argmax_1024(const float* __restrict__ row, 
     auto take = [&](float v, int i) { if (v > best || (v == best && i < arg)) { best = v; arg = i; } };
     const bool vec = (((uintptr_t)row & 15) == 0);
     const int V4 = vec ? (V >> 2) : 0;
-    for (int i0 = threadIdx.x; i0 < V4; i0 += 4096) {
-        f32x4 v[4];
+    for (int i0 = threadIdx.x; i0 < V4; i0 += 8192) {
+        f32x4 v[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int i = i0 + u * 1024;
             v[u] = (i < V4) ? ((const f32x4*)row)[i] : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
             for (int k = 0; k < 4; ++k) take(v[u][k], (i0 + u * 1024) * 4 + k);
     }

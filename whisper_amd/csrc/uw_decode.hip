@@ -10,6 +10,7 @@
 // (8 for bf16, 16 for f32) each own one 16-byte chunk of a row, so one wave instruction moves 1 KiB.
 #include "uw_common.h"
 #include "uw_kernels.h"
+#include <algorithm>
 
 namespace {
 
@@ -241,6 +242,13 @@ __global__ __launch_bounds__(256) void cross_decode_split_kernel(CrossDecodePara
             if (sub == 0 && r < S) sc[r] = s;
         }
     }
+    // the first round of V rows is requested before the softmax (for up to 8 parts it is the only round)
+    uint4 vv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int r = (u * 4 + wave) * R::RPI + rin;
+        vv[u] = ld_stream(Vh + (long)min(r, S - 1) * ld);
+    }
     __syncthreads();
     const int slot = p.sel_slot[h];
     float* row_out = nullptr;
@@ -270,11 +278,12 @@ __global__ __launch_bounds__(256) void cross_decode_split_kernel(CrossDecodePara
 #pragma unroll
     for (int e = 0; e < R::E; ++e) acc[e] = 0.f;
     for (int r0 = 0; r0 < S; r0 += rows_per_round) {
-        uint4 vv[U];
+        if (r0 > 0) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
-            vv[u] = ld_stream(Vh + (long)min(r, S - 1) * ld);
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+                vv[u] = ld_stream(Vh + (long)min(r, S - 1) * ld);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -301,38 +310,64 @@ __global__ __launch_bounds__(256) void cross_decode_split_kernel(CrossDecodePara
     if (tid == 65) ws[1] = (red[4] + red[5]) + (red[6] + red[7]);
 }
 
-// merges the parts of one (window, head) in part order; grid (H, B), 256 threads
+// merges the parts of one (window, head) in part order; grid (H, B), 256 threads.  Everything the workgroup needs
+// (the parts' maxima and sums, its 64 x n_split accumulators) is requested in one go: the kernel is a handful of
+// dependent memory round trips and nothing else.
 template <typename T>
 __global__ __launch_bounds__(256) void cross_combine_kernel(CrossDecodeParams p)
 {
+    __shared__ float s_m[16], s_l[16];
     const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     if (p.active && !p.active[b]) return;
     const float* ws = p.split_ws + ((long)b * p.H + h) * p.n_split * 66;
+    if (tid < p.n_split) { s_m[tid] = ws[tid * 66]; s_l[tid] = ws[tid * 66 + 1]; }
+    float part[16];
+#pragma unroll
+    for (int z = 0; z < 16; ++z) part[z] = (tid < 64 && z < p.n_split) ? ws[z * 66 + 2 + tid] : 0.f;
+    const int slot = p.sel_slot[h];
+    float* row = nullptr;
+    if (p.rows && slot >= 0) {
+        const int ri = p.row_index[b];
+        if (ri >= 0 && ri < p.n_rows_max) row = p.rows + (long)b * p.rows_sB + (long)slot * p.rows_sSel + (long)ri * p.S;
+    }
+    float rv[8];      // raw scores of an alignment head's row, 256 threads x 8 >= 1500 frames (longer rows loop below)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rv[k] = (row && tid + k * 256 < p.S) ? row[tid + k * 256] : 0.f;
+    __syncthreads();
     float M = -INFINITY;
-    for (int z = 0; z < p.n_split; ++z) M = fmaxf(M, ws[z * 66]);
-    float L = 0.f;
-    for (int z = 0; z < p.n_split; ++z) L += ws[z * 66 + 1] * __expf(ws[z * 66] - M);
+    for (int z = 0; z < p.n_split; ++z) M = fmaxf(M, s_m[z]);
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int z = 0; z < 16; ++z) {
+        if (z < p.n_split) {
+            const float sc = __expf(s_m[z] - M);
+            L += s_l[z] * sc;
+            o += part[z] * sc;
+        }
+    }
     const float inv = 1.0f / L;
     if (tid < 64) {
-        float o = 0.f;
-        for (int z = 0; z < p.n_split; ++z) o += ws[z * 66 + 2 + tid] * __expf(ws[z * 66] - M);
         const long at = p.out_packed ? frag_elem_offset<T>(b, h * 64 + tid, p.d) : (long)b * p.d + h * 64 + tid;
         store_split<T>(p.out, p.out_lo, at, o * inv);
     }
-    const int slot = p.sel_slot[h];
-    if (p.rows && slot >= 0) {
-        const int ri = p.row_index[b];
-        if (ri >= 0 && ri < p.n_rows_max) {
-            float* row = p.rows + (long)b * p.rows_sB + (long)slot * p.rows_sSel + (long)ri * p.S;
-            for (int j = tid; j < p.S; j += 256) row[j] = __expf(row[j] - M) * inv;
-        }
+    if (row) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (tid + k * 256 < p.S) row[tid + k * 256] = __expf(rv[k] - M) * inv;
+        for (int j = tid + 2048; j < p.S; j += 256) row[j] = __expf(row[j] - M) * inv;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // causal self-attention for one new token: grid (H, B), 256 threads; also appends this token's K/V to the cache.
 // Same structure as the cross kernel over the pos+1 cached rows; the row being appended is taken from registers.
-template <typename T>
+// A (window, head) has at most a few hundred cached rows, so a workgroup lives for little more than its memory
+// round trips: with NU > 0 the workgroup covers NU x (4 waves x RPI rows) rows (the launcher picks the smallest NU
+// that covers the longest window) and requests ALL of its K rows at once, then all of its V rows as soon as the K
+// registers are free -- two round trips, the second one under the softmax -- instead of one per 4-load round
+// (single-window decoding: 8.5 -> about 5 us per launch; full batches are bandwidth-bound either way).
+// NU == 0 is the general loop over rounds.
+template <typename T, int NU>
 __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
 {
     using R = Row<T>;
@@ -357,8 +392,11 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
 #pragma unroll
     for (int e = 0; e < R::E; ++e) q[e] = to_f32<T>(qkv[e]);
     const int n = pos + 1;
-    constexpr int U = 4;
+    constexpr int U = NU > 0 ? NU : 4;
     const int rows_per_round = 4 * R::RPI * U;
+    // NU > 0: one round covers max_rows rows; a window beyond the launcher's bound (never in the greedy loop, whose
+    // bound is exact) simply takes further rounds
+    uint4 vv[U];
     for (int r0 = 0; r0 < n; r0 += rows_per_round) {
         uint4 kv[U];
 #pragma unroll
@@ -372,6 +410,15 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
             const int r = r0 + (u * 4 + wave) * R::RPI + rin;
             const float s = row_sum<T>(dot_chunk<T>(kv[u], q));
             if (sub == 0 && r < n) sc[r] = s;
+        }
+    }
+    const bool one_round = NU > 0 && n <= rows_per_round;   // block-uniform
+    if (one_round) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = (u * 4 + wave) * R::RPI + rin;
+            vv[u] = vnew;
+            if (r < pos) vv[u] = ld_stream(Vc + (long)r * ld);
         }
     }
     __syncthreads();
@@ -395,12 +442,13 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
 #pragma unroll
     for (int e = 0; e < R::E; ++e) acc[e] = 0.f;
     for (int r0 = 0; r0 < n; r0 += rows_per_round) {
-        uint4 vv[U];
+        if (!one_round) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = r0 + (u * 4 + wave) * R::RPI + rin;
-            vv[u] = vnew;
-            if (r < pos) vv[u] = ld_stream(Vc + (long)r * ld);
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + (u * 4 + wave) * R::RPI + rin;
+                vv[u] = vnew;
+                if (r < pos) vv[u] = ld_stream(Vc + (long)r * ld);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -522,8 +570,19 @@ int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s)
     UW_REQUIRE(p.qkv && p.kcache && p.vcache && p.out && p.pos && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.n_ctx <= 512 && p.ld_cache >= 64,
                "self_attn_decode: bad arguments");
     const dim3 grid(p.H, p.B);
-    if (dtype == UW_F32) hipLaunchKernelGGL(self_decode_kernel<float>, grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(self_decode_kernel<bf16_t>, grid, dim3(256), 0, s, p);
+    if (dtype == UW_F32) {
+        hipLaunchKernelGGL((self_decode_kernel<float, 0>), grid, dim3(256), 0, s, p);
+    } else {
+        // bf16: one round of NU loads per lane covers NU * 32 rows; max_rows bounds pos + 1 over the windows of the call
+        const int rows = p.max_rows > 0 ? std::min(p.max_rows, p.n_ctx) : p.n_ctx;
+        const int nu = (rows + 31) / 32;
+        if (nu <= 4) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 4>), grid, dim3(256), 0, s, p);
+        else if (nu <= 6) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 6>), grid, dim3(256), 0, s, p);
+        else if (nu <= 8) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 8>), grid, dim3(256), 0, s, p);
+        else if (nu <= 10) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 10>), grid, dim3(256), 0, s, p);
+        else if (nu <= 12) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 12>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((self_decode_kernel<bf16_t, 14>), grid, dim3(256), 0, s, p);
+    }
     UW_LAUNCH_CHECK();
     return UW_OK;
 }

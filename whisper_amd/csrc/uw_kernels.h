@@ -119,6 +119,7 @@ struct SelfDecodeParams {
     long ld_cache = 0;          // row stride of the caches (elements)
     long cache_sB = 0, cache_sH = 0;  // window and head strides of the caches (elements)
     int B = 0, H = 0, d = 0, n_ctx = 0;
+    int max_rows = 0;           // host-side upper bound of pos + 1 over the windows (0: n_ctx); sizes the bf16 kernel's rounds
 };
 int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s);
 
