@@ -1,5 +1,7 @@
-// Development micro-benchmark of the decode-step GEMM shapes with cold weights (rotating copies larger than the
-// Infinity Cache).  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iwhisper_amd/csrc tools/skinny_bench.hip -o tools/_build/skinny_bench
+// Development micro-benchmark of the decode-step products as the step launches them (fragment-major operands, split
+// activations, LayerNorm-fused forms) with cold weights (rotating copies larger than the Infinity Cache).
+// UW_SK_TILE / UW_LN_TILE (e.g. 21 = 2 row tiles x 1 column tile per workgroup) override the tile shapes.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DUW_TUNE -Iwhisper_amd/csrc tools/skinny_bench.hip -o tools/_build/skinny_bench
 #include "../whisper_amd/csrc/uw_gemm.hip"
 #include <stdarg.h>
 #include <vector>
@@ -8,32 +10,40 @@ void uw_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprint
 int main(int argc, char** argv)
 {
     const int M = argc > 1 ? atoi(argv[1]) : 128;
-    struct Shape { int K, N, out_f32, act, res; const char* name; } shapes[] = {
-        {768, 2304, 0, 0, 0, "qkv"}, {768, 768, 1, 0, 1, "out+res"}, {768, 768, 0, 0, 0, "crossq"}, {768, 3072, 0, 1, 0, "fc1"}, {3072, 768, 1, 0, 1, "fc2"}};
+    const int d = argc > 2 ? atoi(argv[2]) : 768;
+    struct Shape { int K, N, ln, act, res; const char* name; } shapes[] = {
+        {d, 3 * d, 1, 0, 0, "qkv (LN)"}, {d, d, 0, 0, 1, "out+res (hi/lo)"}, {d, d, 1, 0, 0, "crossq (LN)"}, {d, 4 * d, 1, 1, 0, "fc1 (LN, hi/lo out)"},
+        {4 * d, d, 0, 0, 1, "fc2 (hi/lo)"}};
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double total = 0;
     for (auto& sh : shapes) {
         const size_t wbytes = (size_t)sh.N * sh.K * 2;
         const int copies = (int)((600u << 20) / wbytes) + 1;
-        char *W, *A; float *C, *bias;
-        CK(hipMalloc(&W, wbytes * copies)); CK(hipMalloc(&A, (size_t)M * sh.K * 4)); CK(hipMalloc(&C, (size_t)M * sh.N * 4)); CK(hipMalloc(&bias, sh.N * 4));
-        CK(hipMemset(W, 0, wbytes * copies)); CK(hipMemset(A, 0, (size_t)M * sh.K * 4)); CK(hipMemset(C, 0, (size_t)M * sh.N * 4)); CK(hipMemset(bias, 0, sh.N * 4));
-        GemmParams p; p.A = A; p.C = C; p.bias = bias; p.lda = sh.K; p.ldb = sh.K; p.ldc = sh.N; p.ldr = sh.N; p.M = M; p.N = sh.N; p.K = sh.K;
-        p.bias_mode = 1; p.act = sh.act; p.ab_packed = getenv("PACKED") ? 1 : 0; p.c_packed = (p.ab_packed && sh.act) ? 1 : 0;
-        if (getenv("LN") && !sh.res) { p.ln_fused = 1; p.wsum = bias; p.ab_packed = 1; }
-        if (p.ab_packed && sh.res) p.c_xlayout = 1; p.residual = sh.res ? C : nullptr;
+        char *W, *A, *A2; float *C, *bias; char* C2;
+        const size_t abytes = (size_t)((M + 15) & ~15) * sh.K * 4;
+        CK(hipMalloc(&W, wbytes * copies)); CK(hipMalloc(&A, abytes)); CK(hipMalloc(&A2, abytes)); CK(hipMalloc(&C, (size_t)128 * sh.N * 4)); CK(hipMalloc(&C2, (size_t)128 * sh.N * 4));
+        CK(hipMalloc(&bias, sh.N * 4 + sh.K * 4));
+        CK(hipMemset(W, 0x11, wbytes * copies)); CK(hipMemset(A, 0x11, abytes)); CK(hipMemset(A2, 0x11, abytes)); CK(hipMemset(C, 0, (size_t)128 * sh.N * 4)); CK(hipMemset(bias, 0, sh.N * 4 + sh.K * 4));
+        GemmParams p; p.A = A; p.C = C; p.bias = bias; p.ldc = sh.N; p.ldr = sh.N; p.M = M; p.N = sh.N; p.K = sh.K;
+        p.bias_mode = 1; p.act = sh.act; p.ab_packed = 1;
+        int out_f32 = 0;
+        if (sh.ln) { p.ln_fused = 1; p.wsum = bias; p.gamma = bias + sh.N; p.c_packed = sh.act ? 1 : 0; p.C_lo = sh.act ? C2 : nullptr; }
+        else { p.A_lo = A2; p.c_xlayout = 1; p.residual = C; out_f32 = 1; }
         const int iters = 400;
         for (int rep = 0; rep < 2; ++rep) {
             if (rep == 1) CK(hipEventRecord(e0, s));
             for (int i = 0; i < iters; ++i) {
                 p.B = W + (size_t)(i % copies) * wbytes;
-                if (uw_gemm_skinny(UW_BF16, sh.out_f32, p, s)) return 1;
+                if (uw_gemm_skinny(UW_BF16, out_f32, p, s)) return 1;
             }
         }
         CK(hipEventRecord(e1, s)); CK(hipStreamSynchronize(s));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("%-8s M=%d K=%d N=%d  %.2f us/launch (cold W, %d copies)\n", sh.name, M, sh.K, sh.N, 1e3 * ms / iters, copies);
-        CK(hipFree(W)); CK(hipFree(A)); CK(hipFree(C)); CK(hipFree(bias));
+        printf("%-22s M=%d K=%d N=%d  %.2f us/launch\n", sh.name, M, sh.K, sh.N, 1e3 * ms / iters);
+        total += 1e3 * ms / iters;
+        CK(hipFree(W)); CK(hipFree(A)); CK(hipFree(A2)); CK(hipFree(C)); CK(hipFree(C2)); CK(hipFree(bias));
     }
+    printf("layer total (out+res twice): %.2f us\n", total + 0);
     return 0;
 }

@@ -419,14 +419,22 @@ int gemm_step_ln(uw_ctx* c, const float* x, const void* Wp, const float* gamma, 
 }
 
 // logits[m][:] = LayerNorm(x[m]) . tok_emb^T for M rows of the residual stream held in the step's x layout.  For bf16
-// compute the normalised row is written as a [hi | lo] pair and the product runs over 2 d with the embedding
-// repeating (GemmParams::kwrap_b), so the logits see no bf16-rounded activations; `ln` is scratch for [M][2 d].
+// compute the normalised row is written as a [hi | lo] pair and multiplied by uw_gemm_rows_hilo, so the logits see no
+// bf16-rounded activations; `ln` is scratch for [M][2 d].
 int logits_from_x(uw_ctx* c, const float* x, int M, void* ln, float* logits, hipStream_t s)
 {
-    const int d = c->d, split = c->dt == UW_BF16 ? 1 : 0, w = split ? 2 : 1;
+    const int d = c->d, split = c->dt == UW_BF16 ? 1 : 0;
     RUN(uw_layernorm(c->dt, x, ln, nullptr, c->dec_ln_g, c->dec_ln_b, M, d, s, 0, 1, split));
-    return gemm(c, ln, w * d, c->tok_emb, d, logits, c->logits_ld, true, M, c->V, w * d, nullptr, 0, nullptr, 0, s, 1, 0, 0, 0, 0, 1, 0, 0,
-                split ? d : 0);
+    if (split) {
+        for (int off = 0; off < M; off += 128) {
+            GemmParams p;
+            p.A = (const char*)ln + (size_t)off * 2 * d * c->es; p.B = c->tok_emb; p.C = logits + (long)off * c->logits_ld;
+            p.lda = 2 * d; p.ldb = d; p.ldc = c->logits_ld; p.M = std::min(128, M - off); p.N = c->V; p.K = d;
+            RUN(uw_gemm_rows_hilo(p, s));
+        }
+        return UW_OK;
+    }
+    return gemm(c, ln, d, c->tok_emb, d, logits, c->logits_ld, true, M, c->V, d, nullptr, 0, nullptr, 0, s);
 }
 
 // brackets for the secondary spans: begin returns the event slot (or -1), end closes it

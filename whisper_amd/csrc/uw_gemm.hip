@@ -523,6 +523,112 @@ template <typename T, typename TC> int launch_duo(const GemmParams& p, hipStream
     return UW_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Few rows against a tall weight matrix with split activations: C[m][n] = sum_k (A_hi[m][k] + A_lo[m][k]) * B[n][k],
+// M <= 128, bf16 operands, f32 C -- the tied output projection of a decode step (N = vocabulary).  One workgroup per
+// 256 columns, 8 waves of 64 x 64: a stage holds the hi rows, the lo rows and 256 weight rows of one 32-deep K-step,
+// and every weight fragment is multiplied with both.  Against running the tile kernel over [hi | lo] with the weights
+// repeating, the weight tile crosses into LDS once instead of twice and a workgroup's copy of the activations serves
+// 256 columns instead of 128: the product is bound by what a CU can take in through the LDS DMA, and this halves it.
+constexpr int HLM = 128, HLN = 256;
+constexpr int HL_A = HLM * K3_ROW, HL_B = HLN * K3_ROW, HL_STAGE = 2 * HL_A + HL_B;   // 8 + 8 + 16 KiB
+constexpr int HL_NSTAGE = 3;
+
+__global__ __launch_bounds__(512) void gemm_rows_hilo_kernel(GemmParams p)
+{
+    using T = bf16_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int E = 8, KT = K3_ROW / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * HLN;
+    const unsigned lds_base = lds_addr_of(smem) + wave * 1024;
+    const T* __restrict__ A = (const T*)p.A;
+    const T* __restrict__ B = (const T*)p.B + (long)n0 * p.ldb;
+    unsigned offA, offB[2];
+    {
+        const int row = tid >> 2, c = (tid & 3) ^ ((-(row >> 2)) & 3);
+        offA = (unsigned)(((long)min(row, p.M - 1) * p.lda + c * E) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int L = i * 512 + tid, row = L >> 2, c = (L & 3) ^ ((-(row >> 2)) & 3);
+        offB[i] = (unsigned)(((long)(min(n0 + row, p.N - 1) - n0) * p.ldb + c * E) * 2);
+    }
+    auto stage = [&](int kt, int st) {
+        const unsigned hi_dst = lds_base + st * HL_STAGE, lo_dst = hi_dst + HL_A, b_dst = lo_dst + HL_A;
+        const T* ka = A + (long)kt * KT;
+        const T* kb = B + (long)kt * KT;
+        glds16_sv(ka, offA, hi_dst);
+        glds16_sv(ka + p.K, offA, lo_dst);       // the lo half of a row starts K elements after the hi half
+        glds16_sv(kb, offB[0], b_dst);
+        glds16_sv(kb, offB[1], b_dst + 8192);
+    };
+    const int nk = p.K / KT;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) stage(kt + 2, (kt + 2) % HL_NSTAGE);
+        const char* Hs = smem + (kt % HL_NSTAGE) * HL_STAGE;
+        const char* Ls = Hs + HL_A;
+        const char* Bs = Ls + HL_A;
+        const int pos = (fg ^ ((-(frow >> 2)) & 3)) << 4;
+        uint4 ah[4], al[4], bf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ah[t] = *(const uint4*)(Hs + (wr * 64 + t * 16 + frow) * K3_ROW + pos);
+            al[t] = *(const uint4*)(Ls + (wr * 64 + t * 16 + frow) * K3_ROW + pos);
+            bf[t] = *(const uint4*)(Bs + (wc * 64 + t * 16 + frow) * K3_ROW + pos);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) {
+                mma16<T>(bf[tn], ah[tm], acc[tm][tn]);
+                mma16<T>(bf[tn], al[tm], acc[tm][tn]);
+            }
+    }
+    // epilogue: two halves of 32 rows per wave through the idle ring, whole 256-byte row segments to memory
+    __syncthreads();
+    float* ep = (float*)smem + wave * (32 * EP_PITCH);
+    float* __restrict__ C = (float*)p.C;
+    const int nbase = n0 + wc * 64;
+    const bool vec_ok = (p.ldc & 3) == 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+            const int tm = half * 2 + t2, ml = t2 * 16 + frow;
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) *(f32x4*)(ep + ml * EP_PITCH + tn * 16 + fg * 4) = acc[tm][tn];
+        }
+        const int mbase = wr * 64 + half * 32;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int ml = it * 4 + (lane >> 4), nl = (lane & 15) * 4;
+            const int m = mbase + ml, n = nbase + nl;
+            if (m >= p.M || n >= p.N) continue;
+            const f32x4 v = *(const f32x4*)(ep + ml * EP_PITCH + nl);
+            if (vec_ok && n + 3 < p.N) {
+                *(f32x4*)(C + (long)m * p.ldc + n) = v;
+            } else {
+                for (int r = 0; r < 4 && n + r < p.N; ++r) C[(long)m * p.ldc + n + r] = v[r];
+            }
+        }
+    }
+}
+
 template <typename T, typename TC> int launch_big(const GemmParams& p, hipStream_t s)
 {
     constexpr int KT = KB / (int)sizeof(T);
@@ -961,6 +1067,19 @@ template <typename T, typename TC> int launch_step_ln(const GemmParams& p, hipSt
     UW_REQUIRE(!p.C_lo || (p.c_packed && sizeof(TC) == 2), "LayerNorm-fused gemm: a lo plane goes with packed bf16 output");
     // measured on MI355X at M = 128: the f32 operand and its bf16 split are amortised over four column tiles when
     // N is wide; a narrow N keeps 16-row workgroups so that the grid still covers most CUs
+#ifdef UW_TUNE   // development builds only (tools/skinny_bench.hip): tile shape from the environment
+    if (getenv("UW_LN_TILE")) {
+        const int t = atoi(getenv("UW_LN_TILE"));
+        if (t == 11) return launch_step_ln_mt<T, TC, 1, 1>(p, s);
+        if (t == 12) return launch_step_ln_mt<T, TC, 1, 2>(p, s);
+        if (t == 14) return launch_step_ln_mt<T, TC, 1, 4>(p, s);
+        if (t == 21) return launch_step_ln_mt<T, TC, 2, 1>(p, s);
+        if (t == 22) return launch_step_ln_mt<T, TC, 2, 2>(p, s);
+        if (t == 24) return launch_step_ln_mt<T, TC, 2, 4>(p, s);
+        if (t == 41) return launch_step_ln_mt<T, TC, 4, 1>(p, s);
+        if (t == 42) return launch_step_ln_mt<T, TC, 4, 2>(p, s);
+    }
+#endif
     if (p.M <= 16) return p.N >= 2048 ? launch_step_ln_mt<T, TC, 1, 2>(p, s) : launch_step_ln_mt<T, TC, 1, 1>(p, s);
     if (p.N >= 2048) return launch_step_ln_mt<T, TC, 2, 4>(p, s);
     return launch_step_ln_mt<T, TC, 1, 2>(p, s);
@@ -984,8 +1103,18 @@ template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStr
     if (p.A_lo) {
         if constexpr (sizeof(T) == 2) {
             UW_REQUIRE(p.ab_packed && ((uintptr_t)p.A_lo % 16) == 0, "skinny gemm: split A needs fragment-major operands");
+#ifdef UW_TUNE
+            if (getenv("UW_SK_TILE")) {
+                const int t = atoi(getenv("UW_SK_TILE"));
+                if (t == 11) return launch_skinny_hilo<T, TC, 1, 1>(p, s);
+                if (t == 12) return launch_skinny_hilo<T, TC, 1, 2>(p, s);
+                if (t == 21) return launch_skinny_hilo<T, TC, 2, 1>(p, s);
+                if (t == 22) return launch_skinny_hilo<T, TC, 2, 2>(p, s);
+                if (t == 41) return launch_skinny_hilo<T, TC, 4, 1>(p, s);
+            }
+#endif
             if (p.M <= 16) return launch_skinny_hilo<T, TC, 1, 1>(p, s);
-            return launch_skinny_hilo<T, TC, 2, 1>(p, s);
+            return launch_skinny_hilo<T, TC, 1, 2>(p, s);   // measured at M = 128: 16 rows x 32 columns beats 32 x 16 by 8-11 %
         } else {
             UW_REQUIRE(false, "skinny gemm: split A is a bf16 form");
         }
@@ -1009,6 +1138,23 @@ int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
     if (dtype == UW_F32) return launch_skinny<float, float>(p, s);
     if (out_f32) return launch_skinny<bf16_t, float>(p, s);
     return launch_skinny<bf16_t, bf16_t>(p, s);
+}
+
+int uw_gemm_rows_hilo(const GemmParams& p, hipStream_t s)
+{
+    constexpr int KT = K3_ROW / 2;
+    UW_REQUIRE(p.A && p.B && p.C && p.M > 0 && p.M <= HLM && p.N > 0 && p.K > 0 && p.K % KT == 0 && p.lda >= 2l * p.K && p.ldb >= p.K,
+               "gemm_rows_hilo: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
+    UW_REQUIRE((p.lda * 2) % 16 == 0 && (p.ldb * 2) % 16 == 0 && (p.K * 2) % 16 == 0 && ((uintptr_t)p.A % 16) == 0 && ((uintptr_t)p.B % 16) == 0,
+               "gemm_rows_hilo: operand rows must be 16-byte aligned");
+    UW_REQUIRE((long)HLM * p.lda * 2 < (1l << 32) && (long)HLN * p.ldb * 2 < (1l << 32), "gemm_rows_hilo: row stride too large");
+    const size_t lds = (size_t)HL_NSTAGE * HL_STAGE;
+    static PerDeviceFlag attr_set;
+    if (attr_set.first_use())
+        UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rows_hilo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gemm_rows_hilo_kernel, dim3((p.N + HLN - 1) / HLN), dim3(512), lds, s, p);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
 }
 
 int uw_pack_frag(int dtype, const void* src, long ld, void* dst, int R, int K, hipStream_t s)

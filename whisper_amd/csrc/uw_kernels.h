@@ -46,6 +46,9 @@ int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
 // fragment-major layout (frag_elem_offset in uw_common.h; rows padded to 16, lda/ldb unused); with p.c_packed
 // C (compute dtype only) is written in that layout too, ready to be the next product's A.
 int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
+// bf16, M <= 128: C (f32) [M][N] = (A_hi + A_lo) . B^T with A rows stored [hi | lo] (lo starts K elements in, lda >= 2K),
+// B [N][K]; the tied output projection of a decode step.  Uses A, B, C, lda, ldb, ldc, M, N, K of the parameter block.
+int uw_gemm_rows_hilo(const GemmParams& p, hipStream_t s);
 // row-major [R][K] (row stride ld) -> fragment-major, rows zero-padded to a multiple of 16
 int uw_pack_frag(int dtype, const void* src, long ld, void* dst, int R, int K, hipStream_t s);
 
