@@ -576,7 +576,10 @@ int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s)
         // bf16: one round of NU loads per lane covers NU * 32 rows; max_rows bounds pos + 1 over the windows of the call
         const int rows = p.max_rows > 0 ? std::min(p.max_rows, p.n_ctx) : p.n_ctx;
         const int nu = (rows + 31) / 32;
-        if (nu <= 4) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 4>), grid, dim3(256), 0, s, p);
+        // a grid that fills the chip several times over is bandwidth-bound and runs faster with the short rounds
+        // (measured at 128 windows x 12 heads: 18.4 us against 19.6 us per launch)
+        if (p.H * p.B >= 512) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 0>), grid, dim3(256), 0, s, p);
+        else if (nu <= 4) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 4>), grid, dim3(256), 0, s, p);
         else if (nu <= 6) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 6>), grid, dim3(256), 0, s, p);
         else if (nu <= 8) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 8>), grid, dim3(256), 0, s, p);
         else if (nu <= 10) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 10>), grid, dim3(256), 0, s, p);
