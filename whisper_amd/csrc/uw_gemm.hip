@@ -1085,8 +1085,8 @@ template <typename T, typename TC> int launch_step_ln(const GemmParams& p, hipSt
     if (p.M <= 16) return p.N >= 2048 ? launch_step_ln_mt<T, TC, 1, 2>(p, s) : launch_step_ln_mt<T, TC, 1, 1>(p, s);
     // measured at M = 128, K = 768: 16 rows x 48 columns per workgroup for the wide products (6.8 / 7.5 us at N = 2304 /
     // 3072 against 7.6 / 8.2 us with 32 x 64), 16 x 32 for N = K
-    if (p.N >= 2048) return launch_step_ln_mt<T, TC, 1, 3>(p, s);
-    return launch_step_ln_mt<T, TC, 1, 2>(p, s);
+    if (p.N >= 2048 && p.M > 64) return launch_step_ln_mt<T, TC, 1, 3>(p, s);
+    return launch_step_ln_mt<T, TC, 1, 2>(p, s);     // also best for 32 rows at every width tried (512, 768, 1280)
 }
 
 template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStream_t s)
@@ -1112,13 +1112,17 @@ template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStr
                 const int t = atoi(getenv("UW_SK_TILE"));
                 if (t == 11) return launch_skinny_hilo<T, TC, 1, 1>(p, s);
                 if (t == 12) return launch_skinny_hilo<T, TC, 1, 2>(p, s);
+                if (t == 13) return launch_skinny_hilo<T, TC, 1, 3>(p, s);
+                if (t == 14) return launch_skinny_hilo<T, TC, 1, 4>(p, s);
                 if (t == 21) return launch_skinny_hilo<T, TC, 2, 1>(p, s);
                 if (t == 22) return launch_skinny_hilo<T, TC, 2, 2>(p, s);
                 if (t == 41) return launch_skinny_hilo<T, TC, 4, 1>(p, s);
             }
 #endif
-            if (p.M <= 16) return launch_skinny_hilo<T, TC, 1, 1>(p, s);
-            return launch_skinny_hilo<T, TC, 1, 2>(p, s);   // measured at M = 128: 16 rows x 32 columns beats 32 x 16 by 8-11 %
+            // measured: up to 32 rows 16 x 16 tiles are fastest (the grid is still under one workgroup per CU); at M = 128
+            // 16 rows x 32 columns beats 32 x 16 by 8-11 %
+            if (p.M <= 64) return launch_skinny_hilo<T, TC, 1, 1>(p, s);
+            return launch_skinny_hilo<T, TC, 1, 2>(p, s);
         } else {
             UW_REQUIRE(false, "skinny gemm: split A is a bf16 form");
         }
