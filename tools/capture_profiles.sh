@@ -9,12 +9,17 @@ set -o pipefail
 TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out
-BENCH="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1 || exit 1
+BENCH="python3 bench.py --inflight 1 --steps 1 --solo-steps 1 --warmup 1 --no-cpu-baseline"
+# one batch in flight: kernel durations as the roofline figures use them (1 warm-up + 1 + 1 timed passes)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 bench.py --inflight 1 --steps 1 --solo-steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1 || exit 1
 python3 tools/prof_summary.py $OUT/${TAG}_trace 3 > $OUT/${TAG}_bench_small_b128_kernel_trace_summary.txt || exit 1
 rm -rf $OUT/${TAG}_trace
+# the default command (three batches in flight): durations include the time kernels of different batches share the GPU
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace3 -o t -- python3 bench.py --steps 6 --solo-steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace3.log 2>&1 || exit 1
+python3 tools/prof_summary.py $OUT/${TAG}_trace3 10 > $OUT/${TAG}_bench_small_b128_inflight3_kernel_trace_summary.txt || exit 1
+rm -rf $OUT/${TAG}_trace3
 {
-  echo "# rocprofv3 --pmc passes (one counter block per run) over: $BENCH   (2 passes of the path in each run)"
+  echo "# rocprofv3 --pmc passes (one counter block per run) over: $BENCH   (3 passes of the path in each run, one batch in flight)"
   echo "# whisper-small shapes, 128 windows, bf16, 170-token prompt, 128 generated tokens.  FETCH_SIZE / WRITE_SIZE are in KiB;"
   echo "# on gfx950 FETCH_SIZE counts a 128-byte request as 64 bytes for wide coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024."
 } > $OUT/${TAG}_pmc_summary.txt

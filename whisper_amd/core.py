@@ -168,7 +168,8 @@ class _Run:
     # one batch of independent segments -> per segment (new_tokens, text_ids, boundaries)
     def transcribe(self, segments: Sequence[np.ndarray], prompts: Sequence[List[int]]):
         eng = self.eng
-        out = []
+        submit = getattr(eng, "transcribe_windows_async", None)   # an EnginePool keeps several groups in flight
+        pending = []
         for i0 in range(0, len(segments), eng.max_batch):
             segs, prs = segments[i0:i0 + eng.max_batch], prompts[i0:i0 + eng.max_batch]
             stride = max(len(s) for s in segs)
@@ -176,11 +177,15 @@ class _Run:
             for i, s in enumerate(segs):
                 buf[i, :len(s)] = s
             n = torch.tensor([len(s) for s in segs], dtype=torch.int32)
-            res = eng.transcribe_windows(torch.from_numpy(buf).to(eng.device), n, prs, self.max_tokens, self.eot, self.sot,
-                                         self.ts_begin, self.ts_end)
+            args = (torch.from_numpy(buf).to(eng.device), n, prs, self.max_tokens, self.eot, self.sot, self.ts_begin, self.ts_end)
+            pending.append((len(segs), submit(*args) if submit else eng.transcribe_windows(*args)))
+        out = []
+        for count, res in pending:
+            if submit:
+                res = res.result()
             n_new, n_text = res["n_new"].cpu().numpy(), res["n_text"].cpu().numpy()
             new, text, bnd = res["new_tokens"].cpu().numpy(), res["text_ids"].cpu().numpy(), res["boundaries"].cpu().numpy()
-            for i in range(len(segs)):
+            for i in range(count):
                 out.append((new[i, :n_new[i]].tolist(), text[i, :n_text[i]].tolist(), bnd[i, :n_text[i] + 1].tolist()))
         return out
 

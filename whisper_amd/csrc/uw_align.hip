@@ -272,8 +272,10 @@ int uw_dtw_run(const double* cost, const int32_t* n_tok, int B, int n_rows_max, 
     const size_t lds = (size_t)(DTW_MAX_BANDS - 1) * S * 8 + (DTW_MAX_BANDS + 4) * 4 + (size_t)2 * (n_rows_max + S) * 2 + 16;
     UW_REQUIRE(lds <= 160 * 1024, "dtw: S=%d needs %zu bytes of LDS", S, lds);
     static PerDeviceFlag attr_set;
-    if (attr_set.first_use())
+    if (attr_set.pending()) {
         UW_HIP_CHECK(hipFuncSetAttribute((const void*)dtw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set.mark();
+    }
     hipLaunchKernelGGL(dtw_kernel, dim3(B), dim3(64 * DTW_MAX_BANDS), lds, s, cost, n_tok, n_rows_max, S,
                        (uint32_t*)dir_ws, dir_words, boundaries, path_i, path_j, path_len);
     UW_LAUNCH_CHECK();
@@ -290,7 +292,7 @@ static __device__ __align__(256) unsigned char scratch[DTW_STATIC_BYTES];
 int uw_dtw_static_run(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, int32_t* boundaries,
                       int32_t* path_i, int32_t* path_j, int32_t* path_len, hipStream_t s)
 {
-    static void* dev_ptr[64] = {};
+    static std::atomic<void*> dev_ptr[64] = {};   // contexts on several host threads may resolve it twice: same value
     UW_REQUIRE(B > 0 && n_rows_max > 0 && S > 0, "dtw: bad sizes B=%d rows=%d S=%d", B, n_rows_max, S);
     const size_t need = (size_t)B * n_rows_max * uw_dtw_dir_words(S) * 4;
     UW_REQUIRE(need <= DTW_STATIC_BYTES,
@@ -300,13 +302,13 @@ int uw_dtw_static_run(const double* cost, const int32_t* n_tok, int B, int n_row
     int dev = 0;
     UW_HIP_CHECK(hipGetDevice(&dev));
     UW_REQUIRE(dev >= 0 && dev < 64, "uw_dtw_static: device ordinal %d out of range", dev);
-    if (!dev_ptr[dev]) {
-        void* ptr = nullptr;
+    void* ptr = dev_ptr[dev].load(std::memory_order_acquire);
+    if (!ptr) {
         UW_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
         UW_REQUIRE(ptr, "uw_dtw_static: no device address for the scratch array");
-        dev_ptr[dev] = ptr;
+        dev_ptr[dev].store(ptr, std::memory_order_release);
     }
     // every direction word of rows < n_tok[b] is written by the forward sweep before the backtrack reads it, so what
     // an earlier call left in the array does not need clearing
-    return uw_dtw_run(cost, n_tok, B, n_rows_max, S, (uint8_t*)dev_ptr[dev], boundaries, path_i, path_j, path_len, s);
+    return uw_dtw_run(cost, n_tok, B, n_rows_max, S, (uint8_t*)ptr, boundaries, path_i, path_j, path_len, s);
 }

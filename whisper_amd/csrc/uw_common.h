@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 transcription kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -222,16 +223,18 @@ __device__ __forceinline__ int block_argmax_1024(const float* __restrict__ row, 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Function attributes (the dynamic LDS limit) are kept per device: one flag per device ordinal, so a process that
-// owns contexts on several GPUs sets the attribute on each of them.  first_use() is true once per device.
+// owns contexts on several GPUs sets the attribute on each of them.
 struct PerDeviceFlag {
-    bool seen[64] = {};
-    bool first_use()
+    std::atomic<bool> done[64];
+    PerDeviceFlag() { for (auto& d : done) d.store(false); }
+    int dev() const
     {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return true;
-        dev &= 63;
-        if (seen[dev]) return false;
-        seen[dev] = true;
-        return true;
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) return -1;
+        return d & 63;
     }
+    // true until mark() has been called on the current device; contexts on several host threads may both see true and
+    // both set the attribute (harmless), but none launches before its own call has returned
+    bool pending() const { const int d = dev(); return d < 0 || !done[d].load(std::memory_order_acquire); }
+    void mark() { const int d = dev(); if (d >= 0) done[d].store(true, std::memory_order_release); }
 };

@@ -514,8 +514,10 @@ template <typename T, typename TC> int launch_duo(const GemmParams& p, hipStream
                "gemm: operand row stride too large for 32-bit tile offsets");
     const size_t lds = (size_t)NSTAGE3 * STAGE3;
     static PerDeviceFlag attr_set;
-    if (attr_set.first_use())
+    if (attr_set.pending()) {
         UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_duo_kernel<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.mark();
+    }
     const long total = tiles * p.batch;
     const unsigned grid = (unsigned)total;
     hipLaunchKernelGGL((gemm_tn_duo_kernel<T, TC>), dim3(grid), dim3(512), lds, s, p);
@@ -641,8 +643,10 @@ template <typename T, typename TC> int launch_big(const GemmParams& p, hipStream
     UW_REQUIRE(tiles < (1l << 31) && p.batch < 65536, "gemm: grid too large");
     const size_t lds = (size_t)NSTAGE2 * STAGE2;
     static PerDeviceFlag attr_set;
-    if (attr_set.first_use())
+    if (attr_set.pending()) {
         UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_big_kernel<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.mark();
+    }
     hipLaunchKernelGGL((gemm_tn_big_kernel<T, TC>), dim3((unsigned)tiles, (unsigned)p.batch), dim3(512), lds, s, p);
     UW_LAUNCH_CHECK();
     return UW_OK;
@@ -1050,8 +1054,10 @@ template <typename T, typename TC, int MT, int NT> int launch_step_ln_mt(const G
     const size_t lds = (size_t)SK_WAVES * MT * NT * 64 * sizeof(f32x4) + (size_t)SK_WAVES * MT * 16 * 2 * sizeof(float) + (size_t)p.K * sizeof(float);
     const dim3 grid((p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
     static PerDeviceFlag attr_set;
-    if (lds > 64 * 1024 && attr_set.first_use())
+    if (lds > 64 * 1024 && attr_set.pending()) {
         UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_step_ln_kernel<T, TC, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set.mark();
+    }
     hipLaunchKernelGGL((gemm_step_ln_kernel<T, TC, MT, NT>), grid, dim3(64 * SK_WAVES), lds, s, p);
     UW_LAUNCH_CHECK();
     return UW_OK;
@@ -1158,8 +1164,10 @@ int uw_gemm_rows_hilo(const GemmParams& p, hipStream_t s)
     UW_REQUIRE((long)HLM * p.lda * 2 < (1l << 32) && (long)HLN * p.ldb * 2 < (1l << 32), "gemm_rows_hilo: row stride too large");
     const size_t lds = (size_t)HL_NSTAGE * HL_STAGE;
     static PerDeviceFlag attr_set;
-    if (attr_set.first_use())
+    if (attr_set.pending()) {
         UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rows_hilo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set.mark();
+    }
     hipLaunchKernelGGL(gemm_rows_hilo_kernel, dim3((p.N + HLN - 1) / HLN), dim3(512), lds, s, p);
     UW_LAUNCH_CHECK();
     return UW_OK;
