@@ -222,3 +222,29 @@ def test_context_without_alignment_heads_transcribes_untimed():
     finally:
         eng.close()
         ref.close()
+
+
+def test_whisperer_through_engine_pool_equals_single_engine():
+    """Independent chunks (no delimiter) and forced-alignment windows go through an EnginePool several groups at a time;
+    tokens, text and every word time must equal what one engine gives group by group."""
+    from whisper_amd.parallel import EnginePool
+    from whisper_amd.weights import synthetic_state_dict
+    dims = dims_for("micro")
+    sd = synthetic_state_dict(dims, 0, std=0.06)
+    sel = [(0, 1), (1, 0), (1, 1)]
+    tok = MicroTokenizer()
+    audio = np.concatenate([synth_audio(20 + i) for i in range(5)] + [synth_audio(30, 150000)])      # six chunks
+    transcript = " ".join(f"w{i}" for i in range(5, 125))
+    eng = _engine(2)
+    try:
+        want = whisperer("synthetic:micro", audio, max_tokens=24, tokenizer=tok, engine=eng)
+        want_al = whisperer("synthetic:micro", audio, transcript=transcript, tokenizer=tok, engine=eng)
+    finally:
+        eng.close()
+    with EnginePool(dims, sd, inflight=3, dtype="f32", max_batch=2, align_heads=sel) as pool:
+        got = whisperer("synthetic:micro", audio, max_tokens=24, tokenizer=tok, engine=pool)
+        got_al = whisperer("synthetic:micro", audio, transcript=transcript, tokenizer=tok, engine=pool)
+        pieces = list(whisperer("synthetic:micro", audio[:480000], stream=True, max_tokens=16, tokenizer=tok, engine=pool))
+    assert got == want and len(got["tokens"]) == 6 * 20
+    assert got_al == want_al and got_al["words"]
+    assert pieces

@@ -5,7 +5,8 @@ Same arguments, result dictionary, error behaviour and chunk semantics as the re
 `Engine.transcribe_windows`.  Chunks of one audio depend on each other only when a delimiter is set (prefix and
 audio context come from the previous chunk, core.py:1058-1146); without a delimiter they are independent and are
 transcribed as one batch.  Extra keyword-only arguments: `tokenizer` (an openai-whisper style tokenizer; when
-omitted openai-whisper's is loaded as the reference does), `engine` (reuse a loaded Engine), `dtype`, `max_batch`.
+omitted openai-whisper's is loaded as the reference does), `engine` (reuse a loaded Engine or EnginePool), `dtype`,
+`max_batch`, `inflight` (batches of independent windows kept in flight on the GPU; > 1 builds an EnginePool).
 """
 from __future__ import annotations
 
@@ -106,7 +107,7 @@ def _next_prefix(chunk_words: Sequence[Dict], delimiter: str, diarization: bool)
 class _Run:
     """Everything one whisperer() call needs: engine, tokenizer, special ids, prompt builder."""
 
-    def __init__(self, model, language, prompt, max_tokens, tokenizer, engine, dtype, max_batch, onnx_encoder, onnx_decoder):
+    def __init__(self, model, language, prompt, max_tokens, tokenizer, engine, dtype, max_batch, onnx_encoder, onnx_decoder, inflight=1):
         self.model, self.language, self.max_tokens = model, language, max_tokens
         if tokenizer is None:
             tokenizer, self.multilingual = get_tokenizer_for_model(model, language, "transcribe")
@@ -127,7 +128,11 @@ class _Run:
             name, sd = resolve_weights(model, onnx_encoder, onnx_decoder)
             dims = dims_for(name)
             heads = alignment_heads(alignment_heads_key(name, dims.d_model, language), dims.dec_layers, dims.n_heads) or []
-            engine = Engine(dims, sd, dtype=dtype, max_batch=max_batch, align_heads=heads)
+            if inflight > 1:
+                from .parallel import EnginePool
+                engine = EnginePool(dims, sd, inflight=inflight, dtype=dtype, max_batch=max_batch, align_heads=heads)
+            else:
+                engine = Engine(dims, sd, dtype=dtype, max_batch=max_batch, align_heads=heads)
         self.eng = engine
         if n_mels_for(model) != engine.dims.n_mels:
             raise ValueError(f"mel spectrogram final shape validation failed: model string '{model}' implies "
@@ -198,7 +203,7 @@ def whisperer(model: str, audio: Union[str, np.ndarray], language: str = "en", t
               delimiter: Optional[str] = None, prompt: Optional[str] = None, onnx_encoder: Optional[str] = None,
               onnx_decoder: Optional[str] = None, verbose: bool = False, stream: bool = False, max_tokens: int = 448,
               onnx_providers: Optional[List[str]] = None, exclude_providers_on_error: List[str] = ['CoreMLExecutionProvider'],
-              *, tokenizer=None, engine=None, dtype: str = "bf16", max_batch: int = 16
+              *, tokenizer=None, engine=None, dtype: str = "bf16", max_batch: int = 16, inflight: int = 1
               ) -> Union[Dict, Generator[str, None, None]]:
     logger.setLevel(logging.INFO if verbose else logging.WARNING)
     diarization = _is_diarization(delimiter)
@@ -209,7 +214,7 @@ def whisperer(model: str, audio: Union[str, np.ndarray], language: str = "en", t
         raise ValueError("cannot use 'transcript' parameter when 'stream' is true.")
     if transcript is not None:
         prompt, delimiter = None, None
-    run = _Run(model, language, prompt, max_tokens, tokenizer, engine, dtype, max_batch, onnx_encoder, onnx_decoder)
+    run = _Run(model, language, prompt, max_tokens, tokenizer, engine, dtype, max_batch, onnx_encoder, onnx_decoder, inflight)
     big_model = "medium" in model.lower() or "large" in model.lower()
     if diarization and not big_model:
         logger.warning("speaker diarization with `speaker()` and `person()` is only supported by model sizes medium, "
@@ -229,13 +234,22 @@ def _align_transcript(run: _Run, audio: np.ndarray, transcript: str) -> Dict:
         raise RuntimeError(f"transcript encoding failed: {e}")
     windows = A.calculate_sliding_windows_for_alignment(len(audio), tokens)
     eng, prompt = run.eng, run.standard_prompt()[:-1] + [run.ts_begin]
-    results: List[List[Dict]] = []
+    def boundaries_of(e, buf, n, prompts, texts_live):
+        """Teacher-forced rows and DTW for one group of windows, all on one context."""
+        mel = e.mel(buf.to(e.device), n)
+        e.encode(mel)
+        e.cross_kv(len(prompts))
+        e.attn_rows_forced(prompts, texts_live)
+        return e.align(torch.tensor([len(t) for t in texts_live], dtype=torch.int32)).cpu().numpy()
+
+    submit = getattr(eng, "submit", None)      # an EnginePool keeps several groups in flight
+    pending = []
     for i0 in range(0, len(windows), eng.max_batch):
         group = windows[i0:i0 + eng.max_batch]
         texts = [[t for t in tokens[w[2]:w[3]] if run.is_text(t)] for w in group]
         # no alignment heads (unknown model key / mask of another size): every window comes back empty (align.py:595-597)
         live = [k for k, t in enumerate(texts) if t and eng.heads and len(prompt) + len(t) - 1 <= eng.n_text_ctx]
-        group_words: List[List[Dict]] = [[] for _ in group]
+        bnd = None
         if live:
             stride = max(group[k][1] - group[k][0] for k in live)
             buf = np.zeros((len(live), stride), dtype=np.float32)
@@ -243,11 +257,15 @@ def _align_transcript(run: _Run, audio: np.ndarray, transcript: str) -> Dict:
                 seg = audio[group[k][0]:group[k][1]]
                 buf[r, :len(seg)] = seg
             n = torch.tensor([group[k][1] - group[k][0] for k in live], dtype=torch.int32)
-            mel = eng.mel(torch.from_numpy(buf).to(eng.device), n)
-            eng.encode(mel)
-            eng.cross_kv(len(live))
-            eng.attn_rows_forced([prompt] * len(live), [texts[k] for k in live])
-            bnd = eng.align(torch.tensor([len(texts[k]) for k in live], dtype=torch.int32)).cpu().numpy()
+            args = (torch.from_numpy(buf), n, [prompt] * len(live), [texts[k] for k in live])
+            bnd = submit(boundaries_of, *args) if submit else boundaries_of(eng, *args)
+        pending.append((group, texts, live, bnd))
+    results: List[List[Dict]] = []
+    for group, texts, live, bnd in pending:
+        group_words: List[List[Dict]] = [[] for _ in group]
+        if live:
+            if submit:
+                bnd = bnd.result()
             for r, k in enumerate(live):
                 if bnd[r, 0] >= 0:     # -1: DTW found no path for this window (align.py:823-827)
                     group_words[k] = run.words_for(texts[k], bnd[r, :len(texts[k]) + 1].tolist(), group[k][0], 0.0)

@@ -78,14 +78,15 @@ class EnginePool:
             try:
                 with torch.cuda.stream(stream):
                     stream.wait_event(ready)                  # inputs were produced on the submitter's stream
-                    res = getattr(eng, method)(*args, **kwargs)
+                    res = method(eng, *args, **kwargs) if callable(method) else getattr(eng, method)(*args, **kwargs)
                     stream.synchronize()                      # results are complete when the future resolves
                 fut.set_result(res)
             except BaseException as e:                        # noqa: BLE001 -- handed to the waiting caller
                 fut.set_exception(e)
 
-    def submit(self, method: str, *args, **kwargs) -> Future:
-        """Queue `engine.<method>(*args, **kwargs)` on the next free engine; the future resolves to its result."""
+    def submit(self, method, *args, **kwargs) -> Future:
+        """Queue `engine.<method>(*args, **kwargs)` -- or, for a callable, `method(engine, *args, **kwargs)`: a sequence
+        of stage calls that must stay on one context -- on the next free engine; the future resolves to its result."""
         if not self._threads:
             raise RuntimeError("pool is closed")
         fut: Future = Future()
@@ -100,7 +101,7 @@ class EnginePool:
     def transcribe_windows(self, *args, **kwargs) -> Dict[str, torch.Tensor]:
         return self.transcribe_windows_async(*args, **kwargs).result()
 
-    def map(self, method: str, arg_lists: Sequence[Sequence]) -> List:
+    def map(self, method, arg_lists: Sequence[Sequence]) -> List:
         """Run one call per entry of `arg_lists`, `inflight` at a time; results in submission order."""
         return [f.result() for f in [self.submit(method, *a) for a in arg_lists]]
 
