@@ -84,6 +84,7 @@ struct uw_ctx {
     int cross_batch = 0;           // windows covered by the current cross K/V
     int step_rows = 0;             // upper bound of (position + 1) of the next decode step over its windows (0: unknown)
     bool enc_valid = false;
+    long enc_rows = 0;         // rows (windows x frames) of the K-blocked encoder output held in enc_T
     // optional timing of the cross-attention decode kernel (the dominant HBM stream)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // start/stop pairs
@@ -299,6 +300,29 @@ int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
             RUN(uw_pack_frag(c->dt, l.w2, f, l.w2_p, (int)d, (int)f, 0));
         }
     }
+    // The encoder's and the cross K/V projection's tile GEMMs read K-blocked operands ([K / KT][rows][KT], KT = 64
+    // bytes of K: see GemmParams): their weights are re-laid once, here; the activations are produced in that form.
+    {
+        const long f = 4 * d;
+        void* tmp = nullptr;
+        ALLOC(tmp, (size_t)f * d * c->es, false);
+        auto kblock = [&](void* w, long R, long K) -> int {
+            RUN(uw_pack_kblock(c->dt, w, tmp, R, (int)K, 0));
+            UW_HIP_CHECK(hipMemcpyAsync(w, tmp, (size_t)R * K * c->es, hipMemcpyDeviceToDevice, 0));
+            return UW_OK;
+        };
+        for (auto& l : c->enc) {
+            RUN(kblock(l.self.wq, 2 * d, d));
+            RUN(kblock(l.self.wv, d, d));
+            RUN(kblock(l.self.wo, d, d));
+            RUN(kblock(l.w1, f, d));
+            RUN(kblock(l.w2, d, f));
+        }
+        for (auto& l : c->dec) {
+            RUN(kblock(l.cross.wkv, 2 * d, d));
+            RUN(kblock(l.cross.wv, d, d));
+        }
+    }
     const float *dlg = cur.next(), *dlb = cur.next();
     ALLOC(c->dec_ln_g, d * 4, false);
     ALLOC(c->dec_ln_b, d * 4, false);
@@ -465,23 +489,49 @@ int encoder_forward(uw_ctx* c, const float* mel, int B, hipStream_t s)
     // conv2 (k3, stride 2, pad 1) + GELU + positions: row t reads padded rows 2t .. 2t+2
     RUN(gemm(c, c->h1p, 2 * d, c->conv2_w, 3 * d, c->e_x, d, true, S, d, 3 * d, c->conv2_b, 1, c->enc_pos, d, s, B, (long)3002 * d, 0,
              (long)S * d, 0));
+    // Operands of the layer GEMMs are K-blocked (GemmParams::kstep_a): LayerNorm, attention and fc1 write that form,
+    // the weights were re-laid at load time.  kt = elements in 64 bytes; a matrix of R rows has K-steps R * kt apart.
+    const long kt = 64 / (long)c->es;
+    auto product = [&](const void* A, long rowsA, const void* W, long rowsW, void* C, long ldc, bool out_f32, int Mg, int Ng, int Kg,
+                       const float* bias, int act, const float* residual, long c_kblock) -> int {
+        GemmParams p;
+        p.A = A; p.B = W; p.C = C; p.bias = bias; p.residual = residual;
+        p.lda = kt; p.ldb = kt; p.ldc = ldc; p.ldr = ldc;
+        p.kstep_a = rowsA * kt; p.kstep_b = rowsW * kt; p.c_kblock = c_kblock;
+        p.M = Mg; p.N = Ng; p.K = Kg; p.batch = 1;
+        p.bias_mode = bias ? 1 : 0; p.act = act;
+        return uw_gemm(c->dt, out_f32 ? 1 : 0, p, s);
+    };
+    // V^T[b] = Wv X[b]^T + bv (rows = model columns): the weights are the A operand, window b's rows of X the B operand
+    auto vt_product = [&](const void* Wv, const void* X, void* VT, const float* bv) -> int {
+        GemmParams p;
+        p.A = Wv; p.B = X; p.C = VT; p.bias = bv;
+        p.lda = kt; p.ldb = kt; p.ldc = c->Spad;
+        p.kstep_a = (long)d * kt; p.kstep_b = M * kt;
+        p.sA = 0; p.sB = (long)S * kt; p.sC = (long)d * c->Spad;
+        p.M = d; p.N = S; p.K = d; p.batch = B;
+        p.bias_mode = 2;
+        return uw_gemm(c->dt, 0, p, s);
+    };
     for (auto& l : c->enc) {
-        RUN(uw_layernorm(c->dt, c->e_x, c->e_ln, nullptr, l.self.ln_g, l.self.ln_b, M, d, s));
-        RUN(gemm(c, c->e_ln, d, l.self.wq, d, c->e_qk, 2 * d, false, (int)M, 2 * d, d, l.self.bq, 0, nullptr, 0, s));
-        RUN(gemm(c, l.self.wv, d, c->e_ln, d, c->e_vt, c->Spad, false, d, S, d, l.self.bv, 0, nullptr, 0, s, B, 0, (long)S * d,
-                 (long)d * c->Spad, 0, 2));
+        RUN(uw_layernorm(c->dt, c->e_x, c->e_ln, nullptr, l.self.ln_g, l.self.ln_b, M, d, s, 2));
+        RUN(product(c->e_ln, M, l.self.wq, 2 * d, c->e_qk, 2 * d, false, (int)M, 2 * d, d, l.self.bq, 0, nullptr, 0));
+        RUN(vt_product(l.self.wv, c->e_ln, c->e_vt, l.self.bv));
         AttnParams a;
         a.Q = c->e_qk; a.K = (char*)c->e_qk + (size_t)d * c->es; a.VT = c->e_vt; a.O = c->e_attn;
         a.ldq = a.ldk = 2 * d; a.ldvt = c->Spad; a.ldo = d;
         a.sQ = a.sK = (long)S * 2 * d; a.sVT = (long)d * c->Spad; a.sO = (long)S * d;
         a.B = B; a.H = H; a.Sq = S; a.Sk = S; a.causal = 0;
+        a.o_kblock = M;
         RUN(uw_flash_attention(c->dt, a, s));
-        RUN(gemm(c, c->e_attn, d, l.self.wo, d, c->e_x, d, true, (int)M, d, d, l.self.bo, 0, c->e_x, d, s));
-        RUN(uw_layernorm(c->dt, c->e_x, c->e_ln, nullptr, l.ln2_g, l.ln2_b, M, d, s));
-        RUN(gemm(c, c->e_ln, d, l.w1, d, c->e_mlp, 4 * d, false, (int)M, 4 * d, d, l.b1, 1, nullptr, 0, s));
-        RUN(gemm(c, c->e_mlp, 4 * d, l.w2, 4 * d, c->e_x, d, true, (int)M, d, 4 * d, l.b2, 0, c->e_x, d, s));
+        RUN(product(c->e_attn, M, l.self.wo, d, c->e_x, d, true, (int)M, d, d, l.self.bo, 0, c->e_x, 0));
+        RUN(uw_layernorm(c->dt, c->e_x, c->e_ln, nullptr, l.ln2_g, l.ln2_b, M, d, s, 2));
+        RUN(product(c->e_ln, M, l.w1, 4 * d, c->e_mlp, 4 * d, false, (int)M, 4 * d, d, l.b1, 1, nullptr, M));
+        RUN(product(c->e_mlp, M, l.w2, d, c->e_x, d, true, (int)M, d, 4 * d, l.b2, 0, c->e_x, 0));
     }
-    RUN(uw_layernorm(c->dt, c->e_x, c->enc_T, c->enc_out32, c->enc_ln_g, c->enc_ln_b, M, d, s));
+    // the encoder output: f32 row-major for callers, compute dtype K-blocked for the cross K/V projection
+    RUN(uw_layernorm(c->dt, c->e_x, c->enc_T, c->enc_out32, c->enc_ln_g, c->enc_ln_b, M, d, s, 2));
+    c->enc_rows = M;
     c->enc_valid = true;
     return UW_OK;
 }
@@ -493,14 +543,29 @@ size_t self_kv_layer_bytes(const uw_ctx* c) { return (size_t)c->Bm * c->Tm * 2 *
 int cross_kv_project(uw_ctx* c, int B, hipStream_t s)
 {
     const int d = c->d, S = c->S;
+    const long kt = 64 / (long)c->es, M = (long)B * S;
+    UW_REQUIRE(c->enc_rows == M, "cross_kv: the encoder output in the context holds %ld rows, this call needs %ld", c->enc_rows, M);
     for (size_t li = 0; li < c->dec.size(); ++li) {
         auto& a = c->dec[li].cross;
         void* kv = (char*)c->cross_kv + li * cross_kv_layer_bytes(c);
         void* vt = (char*)c->cross_vt + li * cross_vt_layer_bytes(c);
         // K|V head-contiguous: window b, group g (K heads, then V heads), frame t at ((b*2H + g)*S + t)*64
-        RUN(gemm(c, c->enc_T, d, a.wkv, d, kv, 64, false, S, 2 * d, d, a.bkv, 0, nullptr, 0, s, B, (long)S * d, 0, (long)S * 2 * d, 0, 1,
-                 (long)S * 64));
-        RUN(gemm(c, a.wv, d, c->enc_T, d, vt, c->Spad, false, d, S, d, a.bv, 0, nullptr, 0, s, B, 0, (long)S * d, (long)d * c->Spad, 0, 2));
+        GemmParams p;
+        p.A = c->enc_T; p.B = a.wkv; p.C = kv; p.bias = a.bkv;
+        p.lda = kt; p.ldb = kt; p.ldc = 64;
+        p.kstep_a = M * kt; p.kstep_b = 2l * d * kt;
+        p.sA = (long)S * kt; p.sB = 0; p.sC = (long)S * 2 * d;
+        p.M = S; p.N = 2 * d; p.K = d; p.batch = B;
+        p.bias_mode = 1; p.c_group = (long)S * 64;
+        RUN(uw_gemm(c->dt, 0, p, s));
+        GemmParams q;
+        q.A = a.wv; q.B = c->enc_T; q.C = vt; q.bias = a.bv;
+        q.lda = kt; q.ldb = kt; q.ldc = c->Spad;
+        q.kstep_a = (long)d * kt; q.kstep_b = M * kt;
+        q.sA = 0; q.sB = (long)S * kt; q.sC = (long)d * c->Spad;
+        q.M = d; q.N = S; q.K = d; q.batch = B;
+        q.bias_mode = 2;
+        RUN(uw_gemm(c->dt, 0, q, s));
     }
     c->cross_batch = B;
     return UW_OK;
@@ -936,7 +1001,10 @@ int uw_cross_kv(uw_ctx* c, const float* enc_states, int B, void* stream)
     RUN(check_batch(c, B));
     hipStream_t s = (hipStream_t)stream;
     if (enc_states) {
-        RUN(uw_convert(c->dt, enc_states, c->enc_T, (long)B * c->S * c->d, 1.f, s));
+        // row-major in the compute dtype (parked in the LayerNorm scratch), then K-blocked as the projection reads it
+        RUN(uw_convert(c->dt, enc_states, c->e_ln, (long)B * c->S * c->d, 1.f, s));
+        RUN(uw_pack_kblock(c->dt, c->e_ln, c->enc_T, (long)B * c->S, c->d, s));
+        c->enc_rows = (long)B * c->S;
     } else {
         UW_REQUIRE(c->enc_valid, "uw_cross_kv: no encoder output in the context");
     }

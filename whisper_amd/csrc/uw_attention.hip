@@ -239,7 +239,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     if constexpr (!PROBS) {
         if (q_ok) {
+            constexpr int KT = 64 / (int)sizeof(T);
             T* orow = (T*)p.O + b * p.sO + (long)q_abs * p.ldo + head * 64;
+            const long krow = (long)b * Sq + q_abs;     // K-blocked output: row of the [o_kblock][H * 64] matrix
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -247,12 +249,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     const int hd = 32 * m + 8 * a + 4 * hl;
                     const float v0 = ot[m][4 * a + 0] * inv_l, v1 = ot[m][4 * a + 1] * inv_l;
                     const float v2 = ot[m][4 * a + 2] * inv_l, v3 = ot[m][4 * a + 3] * inv_l;
+                    T* dst = orow + hd;
+                    if (p.o_kblock) {
+                        const int k = head * 64 + hd;
+                        dst = (T*)p.O + ((long)(k / KT) * p.o_kblock + krow) * KT + k % KT;
+                    }
                     if constexpr (sizeof(T) == 4) {
-                        *(f32x4*)((float*)orow + hd) = f32x4{v0, v1, v2, v3};
+                        *(f32x4*)dst = f32x4{v0, v1, v2, v3};
                     } else {
                         union { bf16_t h[4]; uint2 u; } pk;
                         pk.h[0] = (bf16_t)v0; pk.h[1] = (bf16_t)v1; pk.h[2] = (bf16_t)v2; pk.h[3] = (bf16_t)v3;
-                        *(uint2*)((bf16_t*)orow + hd) = pk.u;
+                        *(uint2*)dst = pk.u;
                         if (p.o_split) {   // split activations: lo half of the row, H * 64 columns further
                             union { bf16_t h[4]; uint2 u; } lo;
                             lo.h[0] = (bf16_t)(v0 - (float)pk.h[0]); lo.h[1] = (bf16_t)(v1 - (float)pk.h[1]);
@@ -285,6 +292,7 @@ template <typename T> int launch_flash(const AttnParams& p, hipStream_t s)
     UW_REQUIRE(!p.causal || p.Sk >= p.Sq, "attention: causal needs Sk >= Sq");
     UW_REQUIRE((p.ldo * sizeof(T)) % 8 == 0, "attention: output rows must be 8-byte aligned");
     UW_REQUIRE(!p.o_split || (sizeof(T) == 2 && p.ldo >= 2l * p.H * 64), "attention: split output is a bf16 row of 2 * H * 64 elements");
+    UW_REQUIRE(!p.o_kblock || (!p.o_split && !p.sq_len && p.o_kblock >= (long)p.B * p.Sq), "attention: K-blocked output covers B * Sq rows, unsplit");
     const dim3 grid((p.Sq + 127) / 128, p.H, p.B);
     hipLaunchKernelGGL((attention_kernel<T, false>), grid, dim3(256), 4 * Lay<T>::TILE, s, p, ProbParams());
     UW_LAUNCH_CHECK();

@@ -55,7 +55,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             if (y32) ((f32x4*)(y32 + row * d))[c] = o;
             if (y) {
                 // four consecutive columns never straddle a 16-byte chunk, so they stay contiguous when packed
-                T* dst = packed ? y + frag_elem_offset<T>(row, c * 4, d) : y + row * (split ? 2 * d : d) + c * 4;
+                constexpr int KT = 64 / (int)sizeof(T);
+                T* dst = packed == 2 ? y + ((long)((c * 4) / KT) * rows + row) * KT + (c * 4) % KT
+                       : packed      ? y + frag_elem_offset<T>(row, c * 4, d)
+                                     : y + row * (split ? 2 * d : d) + c * 4;
                 if constexpr (sizeof(T) == 4) {
                     *(f32x4*)dst = o;
                 } else {

@@ -365,8 +365,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int wrap_a = p.kwrap_a ? p.kwrap_a / KT : 0x7fffffff, wrap_b = p.kwrap_b ? p.kwrap_b / KT : 0x7fffffff;
     auto stage = [&](int kt, int st) {
         const unsigned a_dst = lds_base + st * STAGE3, b_dst = a_dst + A3_BYTES;
-        const T* ka = baseA + (long)(kt >= wrap_a ? kt - wrap_a : kt) * KT;
-        const T* kb = baseB + (long)(kt >= wrap_b ? kt - wrap_b : kt) * KT;
+        const T* ka = baseA + (long)(kt >= wrap_a ? kt - wrap_a : kt) * (p.kstep_a ? p.kstep_a : KT);
+        const T* kb = baseB + (long)(kt >= wrap_b ? kt - wrap_b : kt) * (p.kstep_b ? p.kstep_b : KT);
         glds16_sv(ka, offA[0], a_dst);
         glds16_sv(ka, offA[1], a_dst + 8192);
         glds16_sv(kb, offB, b_dst);
@@ -432,6 +432,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     float* ep = (float*)smem + wave * (32 * EP_PITCH);
     TC* __restrict__ C = (TC*)p.C + bz * p.sC;
     const int nbase = n0 + wc * 64;
+    constexpr int KTC = K3_ROW / (int)sizeof(TC);
+    // element offset of C[m][n]; K-blocked output: the 4 or 8 consecutive columns a lane stores stay inside one block
+    auto coff = [&](int m, int n) -> long {
+        return p.c_kblock ? ((long)(n / KTC) * p.c_kblock + m) * KTC + (n % KTC) : c_off(p, m, n);
+    };
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -460,9 +465,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (m >= p.M || n >= p.N) continue;
                 const f32x4 v = *(const f32x4*)(ep + ml * EP_PITCH + nl);
                 if (vec_ok && n + 3 < p.N) {
-                    STORE16_NT((float*)C + c_off(p, m, n), v);
+                    STORE16_NT((float*)C + coff(m, n), v);
                 } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) ((float*)C)[c_off(p, m, n) + r] = v[r];
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) ((float*)C)[coff(m, n) + r] = v[r];
                 }
             }
         } else {
@@ -478,18 +483,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     union { bf16_t h[8]; uint4 u; } pk;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) pk.h[r] = (bf16_t)v[r];
-                    STORE16_NT((bf16_t*)C + c_off(p, m, n), __builtin_bit_cast(f32x4, pk.u));
+                    STORE16_NT((bf16_t*)C + coff(m, n), __builtin_bit_cast(f32x4, pk.u));
                     if (p.c_split) {
                         union { bf16_t h[8]; uint4 u; } lo;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) lo.h[r] = (bf16_t)(v[r] - (float)pk.h[r]);
-                        STORE16_NT((bf16_t*)C + c_off(p, m, n) + p.N, __builtin_bit_cast(f32x4, lo.u));
+                        STORE16_NT((bf16_t*)C + coff(m, n) + p.N, __builtin_bit_cast(f32x4, lo.u));
                     }
                 } else {
                     for (int r = 0; r < 8 && n + r < p.N; ++r) {
                         const TC hi = from_f32<TC>(v[r]);
-                        C[c_off(p, m, n) + r] = hi;
-                        if (p.c_split) C[c_off(p, m, n) + r + p.N] = from_f32<TC>(v[r] - to_f32<TC>(hi));
+                        C[coff(m, n) + r] = hi;
+                        if (p.c_split) C[coff(m, n) + r + p.N] = from_f32<TC>(v[r] - to_f32<TC>(hi));
                     }
                 }
             }
@@ -1185,8 +1190,42 @@ int uw_pack_frag(int dtype, const void* src, long ld, void* dst, int R, int K, h
     return UW_OK;
 }
 
+template <typename T>
+__global__ void pack_kblock_kernel(const T* __restrict__ src, T* __restrict__ dst, long R, int K)
+{
+    constexpr int E = 16 / (int)sizeof(T), KT = 4 * E;
+    const long n = R * (K / E);                      // 16-byte chunks
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / (K / E);
+        const int k = (int)(i % (K / E)) * E;
+        *(uint4*)(dst + ((long)(k / KT) * R + r) * KT + k % KT) = *(const uint4*)(src + r * K + k);
+    }
+}
+
+int uw_pack_kblock(int dtype, const void* src, void* dst, long R, int K, hipStream_t s)
+{
+    const int kt = dtype == UW_F32 ? 16 : 32;
+    UW_REQUIRE(src && dst && src != dst && R > 0 && K > 0 && K % kt == 0, "pack_kblock: K=%d must be a multiple of %d", K, kt);
+    const long n = R * (K / (kt / 4));
+    const int grid = (int)std::min<long>((n + 255) / 256, 65535);
+    if (dtype == UW_F32) hipLaunchKernelGGL(pack_kblock_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, R, K);
+    else hipLaunchKernelGGL(pack_kblock_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, R, K);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
+}
+
 int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
 {
+    if (p.kstep_a || p.kstep_b || p.c_kblock) {
+        // K-blocked operands exist only in the two-workgroup tile kernel
+        const int kt = dtype == UW_F32 ? 16 : 32;
+        UW_REQUIRE(!(p.act && p.residual) && !p.kwrap_a && !p.kwrap_b && !p.c_split && (!p.c_kblock || (!p.c_group && p.batch == 1)) &&
+                       (!p.kstep_a || p.lda == kt) && (!p.kstep_b || p.ldb == kt),
+                   "gemm: unsupported combination with K-blocked operands");
+        if (dtype == UW_F32) return launch_duo<float, float>(p, s);
+        if (out_f32) return launch_duo<bf16_t, float>(p, s);
+        return launch_duo<bf16_t, bf16_t>(p, s);
+    }
     static const int big_mode = getenv("UW_GEMM_BIG") ? atoi(getenv("UW_GEMM_BIG")) : 2;   // 0: 128x128 only, 1: one WG/CU, 2: two WGs/CU
     const bool use_big = big_mode != 0;
     // the two-workgroup kernel folds the residual into the accumulator start, which is only right without an activation

@@ -35,6 +35,11 @@ struct GemmParams {
     //                 c_split: C (bf16) is written as [hi | lo], lo at column n + N (ldc >= 2N).
     //   skinny form:  A_lo / C_lo are the lo planes of fragment-major A / C.
     int kwrap_a = 0, kwrap_b = 0, c_split = 0;
+    // K-blocked operands (two-workgroup tile kernel only).  A [R][K] matrix stored as [K / KT][R][KT], KT = 64 bytes of K:
+    // the 16 rows x 64 bytes one LDS-DMA instruction fetches are then 1 KiB of consecutive bytes (whole cache lines)
+    // instead of sixteen half lines, which nearly doubles what a CU takes in.  kstep_x = R * KT (elements between
+    // K-steps) with ldx = KT marks operand x as K-blocked; c_kblock = rows of C writes the output in the same form.
+    long kstep_a = 0, kstep_b = 0, c_kblock = 0;
     const void* A_lo = nullptr;
     void* C_lo = nullptr;
     long c_group = 0;   // 0: C[m][n] at m*ldc + n.  Else columns are stored in groups of 64 (one attention head):
@@ -51,10 +56,13 @@ int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
 int uw_gemm_rows_hilo(const GemmParams& p, hipStream_t s);
 // row-major [R][K] (row stride ld) -> fragment-major, rows zero-padded to a multiple of 16
 int uw_pack_frag(int dtype, const void* src, long ld, void* dst, int R, int K, hipStream_t s);
+// row-major [R][K] (dtype) -> K-blocked [K / KT][R][KT], KT = 64 bytes of K (see GemmParams::kstep_a)
+int uw_pack_kblock(int dtype, const void* src, void* dst, long R, int K, hipStream_t s);
 
 // ---- uw_elementwise.hip -----------------------------------------------------------------------
 // y[r][:] = LayerNorm(x[r][:]) * gamma + beta, eps 1e-5.  y in dtype; y32 (optional) also gets f32.
-// packed: y is written fragment-major (frag_elem_offset), the A operand of the decode-step GEMMs
+// packed = 1: y is written fragment-major (frag_elem_offset), the A operand of the decode-step GEMMs
+// packed = 2: y is written K-blocked ([d / KT][rows][KT], see GemmParams), the operand form of the encoder's tile GEMMs
 // split (bf16 only): row r of y is [hi | lo], 2d elements (see GemmParams)
 int uw_layernorm(int dtype, const float* x, void* y, float* y32, const float* gamma, const float* beta, long rows,
                  int d, hipStream_t s, int packed = 0, int x_layout = 0, int split = 0);
@@ -90,6 +98,7 @@ struct AttnParams {
     int causal = 0;            // query i sees keys <= i + (Sk - Sq)
     const int32_t* sq_len = nullptr;  // optional per-window valid query count (<= Sq); rows beyond are skipped
     int o_split = 0;           // bf16 only: O rows are [hi | lo], lo at column H*64 + c (ldo >= 2*H*64)
+    long o_kblock = 0;         // > 0: O is written K-blocked (see GemmParams) as a [o_kblock][H*64] matrix, window b at rows b*Sq
 };
 int uw_flash_attention(int dtype, const AttnParams& p, hipStream_t s);
 
