@@ -185,14 +185,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);  // first tile: exp2(-inf) = 0
             const float neg_m = -m_new * LOG2E;
-            float rs = 0.f;
+            // two scores per instruction for the scale-and-shift and for the row sum (v_pk_fma_f32 / v_pk_add_f32): the
+            // vector ALU, not the matrix pipe, is what this loop keeps busiest
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            const f32x2 l2e = {LOG2E, LOG2E}, nm2 = {neg_m, neg_m};
+            f32x2 rs2 = {0.f, 0.f};
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    st[sub][r] = __builtin_amdgcn_exp2f(fmaf(st[sub][r], LOG2E, neg_m));
-                    rs += st[sub][r];
+                for (int r = 0; r < 16; r += 2) {
+                    f32x2 t = __builtin_elementwise_fma(f32x2{st[sub][r], st[sub][r + 1]}, l2e, nm2);
+                    t = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                    st[sub][r] = t[0];
+                    st[sub][r + 1] = t[1];
+                    rs2 += t;
                 }
+            const float rs = rs2[0] + rs2[1];
             l_run = l_run * alpha + rs;
             const bool rescale = __any(m_new != m_run);   // wave-uniform: most tiles leave every maximum unchanged
             m_run = m_new;
