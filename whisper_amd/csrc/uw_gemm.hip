@@ -379,6 +379,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // epilogue (a tile's residual is read before any workgroup writes that tile, so C may alias the residual)
     const float* __restrict__ R = p.residual ? p.residual + bz * p.sR : nullptr;
     const bool r_vec = (p.ldr & 3) == 0;
+    // f32 output with a residual of the same row pitch (the residual stream updated in place): the residual is read in
+    // the epilogue, by the lanes and in the whole-row segments that store the result, instead of as 64-byte pieces of
+    // sixteen rows per instruction in front of the loop
+    const bool r_late = sizeof(TC) == 4 && R && r_vec && p.ldr == p.ldc && !p.c_group && !p.c_kblock && (p.ldc & 3) == 0;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             } else {
                 acc[i][j] = f32x4{bias_m, bias_m, bias_m, bias_m};
             }
-            if (R && m < p.M) {
+            if (R && !r_late && m < p.M) {
                 if (r_vec && n + 3 < p.N) acc[i][j] += *(const f32x4*)(R + (long)m * p.ldr + n);
                 else
 #pragma unroll
@@ -458,12 +462,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int mbase = m0 + wr * 64 + half * 32;
         if constexpr (sizeof(TC) == 4) {
             const bool vec_ok = (p.ldc & 3) == 0;
+            f32x4 rr[8];
+            if (r_late) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int m = mbase + it * 4 + (lane >> 4), n = nbase + (lane & 15) * 4;
+                    rr[it] = (m < p.M && n + 3 < p.N) ? *(const f32x4*)(R + (long)m * p.ldr + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int ml = it * 4 + (lane >> 4), nl = (lane & 15) * 4;
                 const int m = mbase + ml, n = nbase + nl;
                 if (m >= p.M || n >= p.N) continue;
-                const f32x4 v = *(const f32x4*)(ep + ml * EP_PITCH + nl);
+                f32x4 v = *(const f32x4*)(ep + ml * EP_PITCH + nl);
+                if (r_late) {
+                    if (n + 3 < p.N) v += rr[it];
+                    else
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (n + r < p.N) ? R[(long)m * p.ldr + n + r] : 0.f;
+                }
                 if (vec_ok && n + 3 < p.N) {
                     STORE16_NT((float*)C + coff(m, n), v);
                 } else {
