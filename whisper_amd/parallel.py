@@ -46,7 +46,7 @@ class EnginePool:
 
     Batches handed to `submit` run concurrently, one per engine; results are identical to a single engine's (every
     context computes alone, on its own buffers -- only the GPU's time is shared).  Measured on whisper-small shapes,
-    128 windows per batch: 328 ms per batch with one in flight, 277 ms with two, 270 ms with three.  Each context holds
+    128 windows per batch: 324 ms per batch with one in flight, 283 ms with two, 275 ms with three.  Each context holds
     its own weights and caches (about 20 GB at 128 windows of whisper-small), which is what a 288 GB GPU has room for.
 
     The pool answers `max_batch`, `device`, `dims`, `heads` and `transcribe_windows` like an Engine, so it can be passed
