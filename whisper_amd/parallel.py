@@ -56,7 +56,15 @@ class EnginePool:
         from .engine import Engine
         if inflight < 1:
             raise ValueError("inflight must be >= 1")
-        self.engines: List = [Engine(dims, state_dict, **engine_kw) for _ in range(inflight)]
+        self.engines: List = []
+        self._threads: List[threading.Thread] = []
+        try:
+            for _ in range(inflight):
+                self.engines.append(Engine(dims, state_dict, **engine_kw))
+        except BaseException:
+            for e in self.engines:      # a later context did not fit: give the earlier ones back
+                e.close()
+            raise
         e0 = self.engines[0]
         self.dims, self.device, self.dtype, self.max_batch, self.heads, self.n_text_ctx = (
             e0.dims, e0.device, e0.dtype, e0.max_batch, e0.heads, e0.n_text_ctx)
