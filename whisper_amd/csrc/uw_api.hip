@@ -318,10 +318,7 @@ int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
             RUN(kblock(l.w1, f, d));
             RUN(kblock(l.w2, d, f));
         }
-        for (auto& l : c->dec) {
-            RUN(kblock(l.cross.wkv, 2 * d, d));
-            RUN(kblock(l.cross.wv, d, d));
-        }
+        for (auto& l : c->dec) RUN(kblock(l.cross.wkv, 2 * d, d));
     }
     const float *dlg = cur.next(), *dlb = cur.next();
     ALLOC(c->dec_ln_g, d * 4, false);
@@ -557,15 +554,9 @@ int cross_kv_project(uw_ctx* c, int B, hipStream_t s)
         p.sA = (long)S * kt; p.sB = 0; p.sC = (long)S * 2 * d;
         p.M = S; p.N = 2 * d; p.K = d; p.batch = B;
         p.bias_mode = 1; p.c_group = (long)S * 64;
+        // the V half also leaves transposed ([d][Spad] per window), the form the multi-token passes' attention reads
+        p.C2 = vt; p.ldc2 = c->Spad; p.sC2 = (long)d * c->Spad; p.c2_col0 = d;
         RUN(uw_gemm(c->dt, 0, p, s));
-        GemmParams q;
-        q.A = a.wv; q.B = c->enc_T; q.C = vt; q.bias = a.bv;
-        q.lda = kt; q.ldb = kt; q.ldc = c->Spad;
-        q.kstep_a = (long)d * kt; q.kstep_b = M * kt;
-        q.sA = 0; q.sB = (long)S * kt; q.sC = (long)d * c->Spad;
-        q.M = d; q.N = S; q.K = d; q.batch = B;
-        q.bias_mode = 2;
-        RUN(uw_gemm(c->dt, 0, q, s));
     }
     c->cross_batch = B;
     return UW_OK;

@@ -460,6 +460,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         // the wave reads back only what it wrote: LDS operations of one wave are ordered, no barrier needed
         const int mbase = m0 + wr * 64 + half * 32;
+        if (p.C2 && nbase >= p.c2_col0) {
+            // transposed copy: lane -> four consecutive rows m of one column n; eight lanes fill 64 bytes of a C2 row
+            TC* __restrict__ C2 = (TC*)p.C2 + bz * p.sC2;
+            const int m4 = (lane & 7) * 4;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int nl = it * 8 + (lane >> 3);
+                const int m = mbase + m4, n = nbase + nl;
+                if (n >= p.N || m >= p.M) continue;
+                union { TC h[4]; uint2 u2; f32x4 u4; } pk;
+                TC* const h = pk.h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = from_f32<TC>(ep[(m4 + r) * EP_PITCH + nl]);
+                TC* dst = C2 + (long)(n - p.c2_col0) * p.ldc2 + m;
+                if (m + 3 < p.M && (p.ldc2 & 3) == 0) {
+                    if constexpr (sizeof(TC) == 4) *(f32x4*)dst = pk.u4;
+                    else *(uint2*)dst = pk.u2;
+                } else {
+                    for (int r = 0; r < 4 && m + r < p.M; ++r) dst[r] = h[r];
+                }
+            }
+        }
         if constexpr (sizeof(TC) == 4) {
             const bool vec_ok = (p.ldc & 3) == 0;
             f32x4 rr[8];
@@ -1234,6 +1256,8 @@ int uw_pack_kblock(int dtype, const void* src, void* dst, long R, int K, hipStre
 
 int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
 {
+    UW_REQUIRE(!p.C2 || ((p.kstep_a || p.kstep_b) && !out_f32 && p.c2_col0 % 64 == 0 && p.ldc2 > 0),
+               "gemm: the transposed second output exists in the K-blocked two-workgroup form only, from a 64-column boundary");
     if (p.kstep_a || p.kstep_b || p.c_kblock) {
         // K-blocked operands exist only in the two-workgroup tile kernel
         const int kt = dtype == UW_F32 ? 16 : 32;

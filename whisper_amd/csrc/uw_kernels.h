@@ -40,6 +40,11 @@ struct GemmParams {
     // instead of sixteen half lines, which nearly doubles what a CU takes in.  kstep_x = R * KT (elements between
     // K-steps) with ldx = KT marks operand x as K-blocked; c_kblock = rows of C writes the output in the same form.
     long kstep_a = 0, kstep_b = 0, c_kblock = 0;
+    // second, TRANSPOSED copy of the output columns n >= c2_col0 (two-workgroup tile kernel, compute-dtype output):
+    // C2[(n - c2_col0) * ldc2 + m], batch item b at C2 + b * sC2 -- V^T beside the head-contiguous K|V of a projection
+    void* C2 = nullptr;
+    long ldc2 = 0, sC2 = 0;
+    int c2_col0 = 0;
     const void* A_lo = nullptr;
     void* C_lo = nullptr;
     long c_group = 0;   // 0: C[m][n] at m*ldc + n.  Else columns are stored in groups of 64 (one attention head):
