@@ -98,6 +98,27 @@ def test_decode_step_continues_a_prefix(micro, mode, tol):
             assert np.abs(got[b] - ref).max() < tol, (t, b, np.abs(got[b] - ref).max())
 
 
+def test_bf16_greedy_tokens_are_the_argmax_of_the_step_logits(micro):
+    """The greedy loop's fused arg-max / bookkeeping kernel against the exported single step: every generated token must
+    be exactly np.argmax (first index on ties) of the logits that uw_decode_step gives for the same prefix."""
+    eng, enc = micro["bf16"], micro["enc"]
+    sp = MICRO_SPECIALS
+    eng.cross_kv(2, torch.from_numpy(enc).to(DEV))
+    prompts = [[824, 825, 826, 924], [824, 826, 924, 9]]
+    n_gen = 14
+    res = eng.decode_greedy(prompts, len(prompts[0]) + n_gen, -1, sp["sot"], sp["ts_begin"], sp["ts_end"])   # eot never matches
+    got = res["new_tokens"][:, :n_gen].cpu().numpy()
+    assert (res["n_new"].cpu().numpy() == n_gen).all()
+    eng.cross_kv(2, torch.from_numpy(enc).to(DEV))
+    P = len(prompts[0])
+    eng.decoder_forward(torch.tensor([r[: P - 1] for r in prompts], dtype=torch.int32), logits_last=True)
+    last = [r[-1] for r in prompts]
+    for t in range(n_gen):
+        logits = eng.decode_step(torch.tensor(last), torch.tensor([P - 1 + t] * 2)).cpu().numpy()
+        last = [int(np.argmax(logits[b])) for b in range(2)]
+        assert last == got[:, t].tolist(), (t, last, got[:, t].tolist())
+
+
 def _reference_window(om, enc, prompt, max_tokens, sp):
     new = O.greedy_reference_schedule(om, enc, prompt, max_tokens, sp["eot"])
     text = O.filter_text_tokens(new, sp["sot"], sp["ts_begin"], sp["ts_end"])
