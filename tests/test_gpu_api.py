@@ -248,3 +248,32 @@ def test_whisperer_through_engine_pool_equals_single_engine():
     assert got == want and len(got["tokens"]) == 6 * 20
     assert got_al == want_al and got_al["words"]
     assert pieces
+
+
+@pytest.mark.parametrize("sharp", [1.0, 4.0])
+def test_bf16_word_times_within_one_frame_of_fp32(sharp):
+    """The contract's bf16 leg for word timestamps, on the teacher-forced path (forced alignment: the same tokens in both
+    precisions, so only the attention rows, the cost matrix and the DTW path can differ): every word start and end of
+    the bf16 engine lies within one 20 ms frame of the fp32 engine's, whose times equal the CPU oracle's (goldens above).
+    `sharp` scales the cross-attention q and k projections: 1 is the flat landscape of random weights, 4 gives peaked
+    rows; beyond about 8 the scores are so large that bf16 rounding of q.k moves whole paths (not asserted)."""
+    from whisper_amd.engine import Engine
+    dims = dims_for("micro")
+    sd = synthetic_state_dict(dims, 0, std=0.06)
+    for k in list(sd):
+        if "encoder_attn.q_proj.weight" in k or "encoder_attn.k_proj.weight" in k:
+            sd[k] = sd[k] * sharp
+    tok = MicroTokenizer()
+    audio = np.concatenate([synth_audio(7), synth_audio(8, 200000)])
+    transcript = " ".join(f"w{i}" for i in range(5, 65))
+    out = {}
+    for dt in ("f32", "bf16"):
+        eng = Engine(dims, sd, dtype=dt, max_batch=4, align_heads=[(0, 1), (1, 0), (1, 1)])
+        try:
+            out[dt] = whisperer("synthetic:micro", audio, transcript=transcript, tokenizer=tok, engine=eng)
+        finally:
+            eng.close()
+    a, b = out["f32"]["words"], out["bf16"]["words"]
+    assert len(a) == len(b) and len(a) > 20 and [w["text"] for w in a] == [w["text"] for w in b]
+    for x, y in zip(a, b):
+        assert abs(x["start"] - y["start"]) <= 0.0201 and abs(x["end"] - y["end"]) <= 0.0201, (x, y)
