@@ -10,8 +10,8 @@ windows per GPU, inputs resident in HBM.  Metric: audio-seconds per second (RTFx
 Every GPU keeps --inflight batches in flight (whisper_amd.parallel.EnginePool: a context, a HIP stream and a host thread
 per batch), because the kernels of independent batches fill each other's gaps; the K timed steps are K batches pushed
 through that pool.  Per-kernel durations only mean something when the kernel has the GPU to itself, so the `roofline`
-figures come from a second timed region of the same run in which the same batches go through one at a time (the figures
-of the headline region are reported beside them under `overlapped`).
+figures come from another timed region of the same run (ahead of the headline one) in which the same batches go through
+one at a time; the figures of the headline region are reported beside them under `overlapped`.
 
 With --gpus N > 1 and no torch.distributed environment the script starts its own N rank processes (one GPU each,
 before the parent touches any GPU); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
