@@ -277,3 +277,39 @@ def test_bf16_word_times_within_one_frame_of_fp32(sharp):
     assert len(a) == len(b) and len(a) > 20 and [w["text"] for w in a] == [w["text"] for w in b]
     for x, y in zip(a, b):
         assert abs(x["start"] - y["start"]) <= 0.0201 and abs(x["end"] - y["end"]) <= 0.0201, (x, y)
+
+
+def test_onnx_file_pair_runs_on_the_gpu(tmp_path):
+    """The reference's own file contract (encoder_model.onnx + decoder_model_merged.onnx, download.py:217-276) end to end
+    on the GPU: weights read from the files give the same sessions and the same whisperer() result as the state dict they
+    were written from.  The files come from the suite's writer (no exported Whisper graph exists offline), so this pins
+    the plumbing from file to device, not the reader against a real export."""
+    from tests.onnx_writer import write_model
+    from whisper_amd.engine import Engine
+    dims = dims_for("micro")
+    sd = synthetic_state_dict(dims, 0, std=0.06)
+    enc_w = {k: v.numpy() for k, v in sd.items() if k.startswith("model.encoder.")}
+    dec_w = {k: v.numpy() for k, v in sd.items() if k.startswith("model.decoder.")}
+    d = tmp_path / "micro"
+    d.mkdir()
+    ep, dp = str(d / "encoder_model.onnx"), str(d / "decoder_model_merged.onnx")
+    write_model(ep, enc_w, "encoder", "torch", True, False)
+    write_model(dp, dec_w, "decoder", "torch", True, True)
+    tok = MicroTokenizer()
+    audio = np.concatenate([synth_audio(7), synth_audio(8, 200000)])
+    ref_eng = Engine(dims, sd, dtype="f32", max_batch=2, align_heads=[])
+    try:
+        want = whisperer("synthetic:micro", audio, max_tokens=24, tokenizer=tok, engine=ref_eng)
+    finally:
+        ref_eng.close()
+    got = whisperer("micro", audio, max_tokens=24, tokenizer=tok, onnx_encoder=ep, onnx_decoder=dp, dtype="f32", max_batch=2)
+    assert got["tokens"] == want["tokens"] and got["text"] == want["text"] and len(got["tokens"]) == 40
+    enc_s, dec_s = load_onnx_models(ep, dp, onnx_providers=["MI355XExecutionProvider"], model="micro", dtype="f32", max_batch=1)
+    try:
+        assert "use_cache_branch" in [i.name for i in dec_s.get_inputs()]       # merged file name -> merged surface
+        mel = O.log_mel_segment(synth_audio(4), 80).astype(np.float32)
+        hidden = enc_s.run(None, {enc_s.get_inputs()[0].name: mel})[0]
+        om = O.OracleModel(sd, dims.n_heads)
+        assert np.abs(hidden - om.encode(mel)).max() < 3e-4
+    finally:
+        enc_s.engine.close()
