@@ -166,19 +166,42 @@ def cpu_baseline(dims, sd, heads, prompt, n_gen: int, n_windows: int = 2, n_samp
                        f"{[round(x, 1) for x in per_window]}")}
 
 
-def spawn_ranks(args, argv):
+def spawn_ranks(n_ranks, argv, script=None, poll_s=0.2, grace_s=5.0):
     """--gpus N without a torch.distributed environment: start N rank processes, one GPU each.  The parent has not
-    touched a GPU (no HIP call, no torch.cuda query), it only waits and passes rank 0's output through."""
+    touched a GPU (no HIP call, no torch.cuda query); it polls all children, and when one exits non-zero it stops the
+    others (they would otherwise sit in the rendezvous or a barrier until the caller's time limit) and returns that
+    rank's exit code.  Rank 0's output passes through."""
     port = 29500 + os.getpid() % 2000
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
+    failed = 0
+    live = set(range(n_ranks))
+    while live and not failed:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                failed = abs(rc) or 1
+                print(f"bench: rank {r} exited with code {rc}; stopping the other ranks", file=sys.stderr, flush=True)
+                break
+        if live and not failed:
+            time.sleep(poll_s)
+    if failed:
+        for r in live:
+            procs[r].terminate()                 # exact child processes this call started
+        deadline = time.time() + grace_s
+        for r in live:
+            try:
+                procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                procs[r].wait()
+    return failed
 
 
 def main():
@@ -200,7 +223,7 @@ def main():
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(spawn_ranks(args, sys.argv[1:]))
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -221,7 +244,7 @@ def main():
 
     from whisper_amd import engine as E
     from whisper_amd.config import alignment_heads, alignment_heads_key, dims_for
-    from whisper_amd.parallel import EnginePool, gather_results, shard_windows
+    from whisper_amd.parallel import EnginePool, ResultExchange, shard_windows
     from whisper_amd.weights import synthetic_state_dict
 
     dims = dims_for(args.model)
@@ -247,10 +270,11 @@ def main():
     n_samples = torch.full((B,), 480000, dtype=torch.int32, device=device)
     call = (audio, n_samples, prompts, max_tokens, EOT, SOT, TS_BEGIN, TS_END)
 
+    exchange = ResultExchange(n_global, rank, world)   # preallocated buffers, one all_gather per step
+
     def finish(res):
         if world > 1:   # the path's only exchange: gather tokens and boundary frames on every rank
-            small = {k: res[k] for k in ("new_tokens", "boundaries", "n_new", "n_text")}
-            gather_results(small, n_global, rank, world)
+            exchange.gather({k: res[k] for k in ("new_tokens", "boundaries", "n_new", "n_text")})
         return res
 
     def run_steps(k):
@@ -352,7 +376,8 @@ def main():
                   "note": f"same kernel inside the headline region ({args.inflight} batches in flight share the GPU)"}
     line = {
         "metric": "audio-sec/sec (RTFx) whole node, whisper-small greedy + word timestamps",
-        "value": value, "unit": "audio-sec/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": "audio-sec/sec", "n_gpus": world,
+        "ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"whisper-{args.model} shapes (random-init weights), batches of {B} x 30 s synthetic windows per GPU, "

@@ -91,6 +91,12 @@ int uw_decode_greedy(uw_ctx* ctx, const int32_t* prompt_ids, int ld_prompt, cons
                      int max_tokens, int eot, int sot, int ts_begin, int ts_end, int32_t* new_tokens, int32_t* n_new,
                      int32_t* text_ids, int32_t* n_text, void* stream);
 
+/* Per-window outcome of the last uw_decode_greedy / uw_transcribe_windows on this context (both synchronise, so the
+ * answer is complete when they return).  status: i32 [B] HOST array; 0 = decoded normally; 1 = the decoder produced a
+ * logits row holding a NaN and the window stopped there, keeping the tokens generated before it -- the reference's
+ * decoder-run failure inside the generation loop (core.py:948-956, 978-980: error stored, partial tokens kept). */
+int uw_window_status(uw_ctx* ctx, int B, int32_t* status_host);
+
 /* Alignment rows for a given text (forced alignment, align.py:446-471 / 603-630): one teacher-forced pass over
  * prompt + text[:-1]; rows land in the context's rows buffer.  All arrays device except the *_host lengths. */
 int uw_attn_rows_forced(uw_ctx* ctx, const int32_t* prompt_ids, int ld_prompt, const int32_t* prompt_len_host,
@@ -119,7 +125,9 @@ int uw_dtw(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int 
  * uw_dtw; the direction matrix lives in a fixed 16 MiB device array inside the library (one per GPU, held until the
  * process ends), so B * n_rows_max * ceil(S / 16) * 4 bytes must not exceed 16 MiB (e.g. 95 windows x 448 rows x 1500
  * frames) -- larger problems are rejected with an error, use uw_dtw.  The call allocates nothing.  All calls on one GPU
- * share the array: calls that overlap on one GPU (different streams or threads) race. */
+ * share the array: calls that overlap on one GPU (different streams or threads) race.  The array of the CURRENT device is
+ * used, so the device that owns `cost`, the outputs and `stream` must be current when the call is made (a cost matrix on
+ * another device is rejected). */
 #define UW_DTW_STATIC_BYTES (16 << 20)
 int uw_dtw_static(const double* cost, const int32_t* n_tok, int B, int n_rows_max, int S, int32_t* boundaries,
                   int32_t* path_i, int32_t* path_j, int32_t* path_len, void* stream);

@@ -33,3 +33,23 @@ def test_world_size_mismatch_is_rejected_before_any_gpu_work():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_a_failing_rank_stops_the_others_and_sets_the_exit_code(tmp_path):
+    """spawn_ranks: rank 1 exits with code 3 at start-up while rank 0 would wait a minute (as it would in the
+    rendezvous); the launcher must stop rank 0 and report 3 within seconds."""
+    import time
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(3)\n"
+                      "assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "time.sleep(60)\n")
+    t0 = time.time()
+    rc = bench.spawn_ranks(2, [], script=str(script))
+    assert rc == 3 and time.time() - t0 < 20
+
+
+def test_ranks_that_finish_cleanly_give_zero(tmp_path):
+    script = tmp_path / "rank.py"
+    script.write_text("import os\nassert int(os.environ['LOCAL_RANK']) == int(os.environ['RANK'])\n")
+    assert bench.spawn_ranks(3, [], script=str(script)) == 0

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from whisper_amd.parallel import gather_results, shard_windows
+from whisper_amd.parallel import ResultExchange, gather_results, gather_results_per_key, shard_windows
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -33,8 +33,16 @@ def _worker(rank, world, port, n_windows, out_dir):
     mine = shard_windows(n_windows, rank, world)
     res = _fake_transcribe(list(mine))
     full = gather_results(res, n_windows, rank, world)
+    plain = gather_results_per_key(res, n_windows, rank, world)
+    # the per-step exchange: one collective per gather, buffers reused from the second step on
+    ex = ResultExchange(n_windows, rank, world)
+    first = ex.gather(res)
+    send, recv = ex._send, ex._recv
+    again = ex.gather({k: v + 1 for k, v in res.items()})
+    reused = ex._send is send and ex._recv is recv
     if rank == 0:
-        torch.save(full, os.path.join(out_dir, "gathered.pt"))
+        torch.save({"packed": full, "per_key": plain, "first": first, "again": again, "collectives": ex.collectives,
+                    "reused": reused}, os.path.join(out_dir, "gathered.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,4 +61,17 @@ def test_two_rank_gather_matches_single_process(tmp_path):
     got = torch.load(os.path.join(str(tmp_path), "gathered.pt"), weights_only=True)
     ref = _fake_transcribe(list(range(n_windows)))
     for k in ref:
-        assert torch.equal(got[k], ref[k]), k
+        assert torch.equal(got["packed"][k], ref[k]), k             # the packed exchange restores global window order
+        assert torch.equal(got["per_key"][k], ref[k]), k            # ... and equals one all_gather per tensor
+        assert torch.equal(got["first"][k], ref[k]) and torch.equal(got["again"][k], ref[k] + 1), k
+    assert got["collectives"] == 2 and got["reused"]                # one collective per step, no new buffers
+
+
+def test_packed_exchange_rejects_other_dtypes():
+    ex = ResultExchange(4, 0, 2)
+    try:
+        ex._prepare({"x": torch.zeros((2, 3), dtype=torch.float32)}, torch.device("cpu"))
+    except TypeError as e:
+        assert "i32" in str(e)
+    else:
+        raise AssertionError("a float tensor must not be packed into the i32 exchange")

@@ -167,6 +167,7 @@ def test_whisperer_on_gpu_reproduces_reference_core_golden():
     import json
     import os
     from tests.helpers import WordTokenizer
+    from tests.oracle_engine import FaultInjector
     from tests.test_reference_e2e import CASES, GOLD, heads_for
     from whisper_amd import engine as E
     gold = json.load(open(GOLD))
@@ -181,7 +182,9 @@ def test_whisperer_on_gpu_reproduces_reference_core_golden():
             heads = tuple(heads_for(model, dims))      # the mask the reference resolves for this model string ([] on a mismatch)
             if heads not in engines:
                 engines[heads] = E.Engine(dims, sd, dtype="f32", max_batch=2, align_heads=list(heads))
-            res = whisperer(model=model, audio=audio, language="en", tokenizer=WordTokenizer(), engine=engines[heads], **kw)
+            faults = kw.pop("faults", None)     # failure-isolation cases: the same faults, shown by the real engine
+            eng = FaultInjector(engines[heads], **faults) if faults else engines[heads]
+            res = whisperer(model=model, audio=audio, language="en", tokenizer=WordTokenizer(), engine=eng, **kw)
             ref = gold["cases"][name]
             if kw.get("stream"):      # generator mode (core.py:238-536): the yielded pieces, in order
                 assert list(res) == ref["pieces"], name
@@ -313,3 +316,28 @@ def test_onnx_file_pair_runs_on_the_gpu(tmp_path):
         assert np.abs(hidden - om.encode(mel)).max() < 3e-4
     finally:
         enc_s.engine.close()
+
+
+def test_cached_model_files_are_found_without_paths(tmp_path, monkeypatch):
+    """No onnx_encoder / onnx_decoder given: the files the reference keeps under ~/.cache/urro_whisper/models/<name>/ are
+    used (download.py:240-259, merged decoder preferred); nothing is downloaded."""
+    from tests.onnx_writer import write_model
+    from whisper_amd.engine import Engine
+    monkeypatch.setenv("HOME", str(tmp_path))
+    dims = dims_for("micro")
+    sd = synthetic_state_dict(dims, 0, std=0.06)
+    d = tmp_path / ".cache" / "urro_whisper" / "models" / "micro"
+    d.mkdir(parents=True)
+    write_model(str(d / "encoder_model.onnx"), {k: v.numpy() for k, v in sd.items() if k.startswith("model.encoder.")}, "encoder", "torch", True, False)
+    write_model(str(d / "decoder_model_merged.onnx"), {k: v.numpy() for k, v in sd.items() if k.startswith("model.decoder.")}, "decoder", "torch", True, True)
+    tok = MicroTokenizer()
+    audio = synth_audio(9)
+    ref_eng = Engine(dims, sd, dtype="f32", max_batch=1, align_heads=[])
+    try:
+        want = whisperer("synthetic:micro", audio, max_tokens=20, tokenizer=tok, engine=ref_eng)
+    finally:
+        ref_eng.close()
+    got = whisperer("micro", audio, max_tokens=20, tokenizer=tok, dtype="f32", max_batch=1)
+    assert got["tokens"] == want["tokens"] and got["text"] == want["text"]
+    with pytest.raises(FileNotFoundError, match="not found in cache"):
+        whisperer("tiny", audio, max_tokens=20, tokenizer=tok)

@@ -61,3 +61,44 @@ def test_resolve_weights_accepts_onnx_paths(tmp_path):
     assert name == "micro" and torch.equal(got["model.decoder.embed_tokens.weight"], sd["model.decoder.embed_tokens.weight"])
     with pytest.raises(ValueError):
         resolve_weights("tiny", ep, dp)                        # files of another shape than the named model
+
+
+def test_cache_directory_lookup_follows_the_reference(tmp_path, monkeypatch):
+    """get_onnx_model_paths (download.py:217-276) without the download: ~/.cache/urro_whisper/models/<name>/, aliases
+    resolved, '/' -> '--', decoder_model_merged.onnx preferred, user paths only when BOTH exist."""
+    from whisper_amd.model.download import cache_model_dir, get_onnx_model_paths
+    monkeypatch.setenv("HOME", str(tmp_path))
+    root = tmp_path / ".cache" / "urro_whisper" / "models"
+    assert cache_model_dir("Turbo") == str(root / "large-v3-turbo")
+    assert cache_model_dir("someone/My-Model") == str(root / "someone--my-model")
+    with pytest.raises(FileNotFoundError, match="not found in cache"):
+        get_onnx_model_paths("micro")
+    d = root / "micro"
+    d.mkdir(parents=True)
+    (d / "encoder_model.onnx").write_bytes(b"")
+    with pytest.raises(FileNotFoundError):
+        get_onnx_model_paths("micro")                               # no decoder yet
+    (d / "decoder_model.onnx").write_bytes(b"")
+    assert get_onnx_model_paths("micro") == (str(d / "encoder_model.onnx"), str(d / "decoder_model.onnx"))
+    (d / "decoder_model_merged.onnx").write_bytes(b"")
+    assert get_onnx_model_paths("micro")[1] == str(d / "decoder_model_merged.onnx")
+    # a user path that does not exist sends the lookup to the cache; two existing ones win over it
+    assert get_onnx_model_paths("micro", str(tmp_path / "nope.onnx"), str(d / "decoder_model.onnx"))[0] == str(d / "encoder_model.onnx")
+    ue, ud = tmp_path / "e.onnx", tmp_path / "d.onnx"
+    ue.write_bytes(b""); ud.write_bytes(b"")
+    assert get_onnx_model_paths("micro", str(ue), str(ud)) == (str(ue), str(ud))
+
+
+def test_resolve_weights_reads_cached_files(tmp_path, monkeypatch):
+    monkeypatch.setenv("HOME", str(tmp_path))
+    dims = dims_for("micro")
+    sd = synthetic_state_dict(dims, seed=8)
+    enc, dec = _split(sd)
+    d = tmp_path / ".cache" / "urro_whisper" / "models" / "micro"
+    d.mkdir(parents=True)
+    write_model(str(d / "encoder_model.onnx"), enc, "encoder")
+    write_model(str(d / "decoder_model_merged.onnx"), dec, "decoder")
+    name, got = resolve_weights("micro")
+    assert name == "micro" and torch.equal(got["model.encoder.conv1.weight"], sd["model.encoder.conv1.weight"])
+    with pytest.raises(FileNotFoundError, match="not found in cache"):
+        resolve_weights("tiny")

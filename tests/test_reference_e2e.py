@@ -31,6 +31,17 @@ CASES = {
     "prompt_delimiter_context": dict(audio_seed=28, n_samples=16000 * 70, max_tokens=40, prompt="w700, w701.", delimiter=" >"),
     # model string that is a head-table key of another size: no alignment, untimed words (align.py:81-84,595-597)
     "mask_mismatch": dict(model="medium", audio_seed=29, n_samples=16000 * 35, max_tokens=20),
+    # failure isolation (core.py:813-837, 934-980, 1009-1044, 578-597): the golden was made with a session stand-in that
+    # raises on the stated runs; `faults` describes the same event as the engine shows it (tests/oracle_engine.py)
+    "fail_encoder_chunk2_hyphen": dict(audio_seed=41, n_samples=16000 * 75, max_tokens=22, delimiter=" -", faults=dict(fail_windows=[2])),
+    "fail_encoder_chunk2_plain": dict(audio_seed=32, n_samples=16000 * 75, max_tokens=22, faults=dict(fail_windows=[2])),
+    "fail_alignment_chunk1": dict(audio_seed=33, n_samples=16000 * 63, max_tokens=24, delimiter=" -", faults=dict(no_align=[1])),
+    "fail_decode_chunk2_step5": dict(audio_seed=34, n_samples=16000 * 63, max_tokens=24, delimiter=" >",
+                                     faults=dict(decode_stop={2: 4}, no_align=[2])),
+    "fail_stream_encoder_chunk2": dict(audio_seed=35, n_samples=16000 * 70, max_tokens=18, delimiter=" -", stream=True,
+                                       faults=dict(fail_windows=[2])),
+    "fail_forced_window2": dict(audio_seed=36, n_samples=16000 * 47, max_tokens=448,
+                                transcript=" ".join(f"w{400 + i}" for i in range(24)) + ".", faults=dict(fail_windows=[2])),
 }
 
 
@@ -46,8 +57,10 @@ def engine():
     sd = synthetic_state_dict(dims, seed=gold["weights"]["seed"], std=gold["weights"]["std"])
     engines = {}
 
-    def get(case_model):
+    def get(case_model, faults=None):
         key = tuple(heads_for(case_model, dims))
+        if faults:      # an engine of its own: the injected faults and the window numbering belong to one run
+            return OracleEngine(dims, sd, list(key), max_batch=2, **faults)
         if key not in engines:
             engines[key] = OracleEngine(dims, sd, list(key), max_batch=2)
         return engines[key]
@@ -62,7 +75,8 @@ def test_whisperer_matches_reference_core(engine, name):
     kw = dict(CASES[name])
     audio = synth_audio(kw.pop("audio_seed"), kw.pop("n_samples"))
     model = kw.pop("model", gold["model"])
-    res = whisperer(model=model, audio=audio, language="en", tokenizer=WordTokenizer(), engine=get_engine(model), **kw)
+    faults = kw.pop("faults", None)
+    res = whisperer(model=model, audio=audio, language="en", tokenizer=WordTokenizer(), engine=get_engine(model, faults), **kw)
     ref = gold["cases"][name]
     if kw.get("stream"):
         assert list(res) == ref["pieces"]

@@ -21,12 +21,31 @@ def _dtw_static(cost, n_tok):
     pi = torch.zeros((B, N + S), dtype=torch.int32, device=DEV)
     pj = torch.zeros((B, N + S), dtype=torch.int32, device=DEV)
     plen = torch.zeros((B,), dtype=torch.int32, device=DEV)
+    call = lambda: L.check(lib.uw_dtw_static(L.ptr(cost), L.ptr(n_tok), B, N, S, L.ptr(bnd), L.ptr(pi), L.ptr(pj), L.ptr(plen),
+                                             L.stream_handle()))
+    call()      # the first call on a device may load the code object and resolve the array's address
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
-    L.check(lib.uw_dtw_static(L.ptr(cost), L.ptr(n_tok), B, N, S, L.ptr(bnd), L.ptr(pi), L.ptr(pj), L.ptr(plen), L.stream_handle()))
+    # free bytes as the DRIVER counts them (hipMemGetInfo): this also sees a hipMalloc made inside the library, which
+    # torch's own allocator statistics would not
+    free_before = torch.cuda.mem_get_info()[0]
+    torch_before = torch.cuda.memory_allocated()
+    call()
     torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == free_before and torch.cuda.memory_allocated() == torch_before
     return bnd, pi, pj, plen
+
+
+def _oracle_window(cost_row, n):
+    """One window through the C restatement of dtw-python's recursion (oracle/dtw_ref.c)."""
+    import os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_build", "libdtw_ref.so")
+    ref = C.CDLL(so)
+    c = np.ascontiguousarray(cost_row[:n])
+    m = c.shape[1]
+    pi, pj, bd = np.zeros(n + m, np.int32), np.zeros(n + m, np.int32), np.zeros(n + 1, np.int32)
+    ln = ref.dtw_symmetric1_ref(c.ctypes.data_as(C.c_void_p), n, m, pi.ctypes.data_as(C.c_void_p), pj.ctypes.data_as(C.c_void_p),
+                                bd.ctypes.data_as(C.c_void_p), 1500)
+    return ln, pi[:ln], pj[:ln], bd
 
 
 def _same(a, b):
@@ -48,11 +67,18 @@ def test_dtw_static_matches_dtw_on_two_calls_in_a_row():
         got = _dtw_static(cost, n_tok)
         _same(got, ref)
         assert (got[3].cpu().numpy()[n > 0] > 0).all()
+        # ... and against the oracle directly: the window with exact ties and the longest one
+        for b in {B // 2, int(np.argmax(n))}:
+            if n[b] == 0:
+                continue
+            ln, oi, oj, obd = _oracle_window(c[b], int(n[b]))
+            assert ln == int(got[3][b]) and np.array_equal(got[1][b, :ln].cpu().numpy(), oi) and np.array_equal(got[2][b, :ln].cpu().numpy(), oj)
+            assert np.array_equal(got[0][b, : n[b] + 1].cpu().numpy(), obd)
 
 
 def test_dtw_static_rejects_sizes_beyond_its_array():
     lib = L.load()
     B, N, S = 128, 448, 1500                      # 21.5 MB of direction matrix > the 16 MiB array
     assert B * N * ((S + 15) // 16) * 4 > 16 << 20
-    rc = lib.uw_dtw_static(None, None, B, N, S, None, None, None, None, None, None)
+    rc = lib.uw_dtw_static(None, None, B, N, S, None, None, None, None, None)
     assert rc != 0 and b"uw_dtw_static" in lib.uw_last_error() and b"fixed device array" in lib.uw_last_error()

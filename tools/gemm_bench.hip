@@ -33,7 +33,8 @@ int main(int argc, char** argv)
         CK(hipMemset(C, 0, (size_t)M * sh.N * 4)); CK(hipMemset(bias, 0, sh.N * 4));
         GemmParams p; p.A = A; p.B = W; p.C = C; p.bias = bias; p.lda = sh.K; p.ldb = sh.K; p.ldc = sh.N; p.ldr = sh.N; p.M = M; p.N = sh.N; p.K = sh.K;
         if (getenv("KBLOCK")) { const int kb = atoi(getenv("KBLOCK")); if (kb & 1) { p.lda = 32; p.kstep_a = (long)M * 32; } if (kb & 2) { p.ldb = 32; p.kstep_b = (long)sh.N * 32; } }
-        p.bias_mode = 1; p.act = getenv("NOACT") ? 0 : sh.act; p.residual = sh.res ? C : nullptr;
+        p.bias_mode = 1; p.act = getenv("NOACT") ? 0 : sh.act;
+        if (getenv("DMA_MODE")) p.act |= atoi(getenv("DMA_MODE"));   // -DUW_TUNE builds: 8 = B pieces only (x3), 16 = one A piece (x6) p.residual = sh.res ? C : nullptr;
         const int iters = 6;
         for (int rep = 0; rep < 2; ++rep) {
             if (rep == 1) CK(hipEventRecord(e0, s));

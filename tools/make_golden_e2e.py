@@ -45,6 +45,17 @@ class _IO:
         self.name = name
 
 
+# Fault injection for the failure-isolation cases: which session runs raise.  Chunks (windows) are counted by encoder
+# runs, one per chunk; `logits_step` = (chunk, k): the k-th logits run of that chunk raises.
+FAULTS = {"encoder_runs": set(), "attn_chunks": set(), "logits_step": None}
+STATE = {"encoder_runs": 0, "logits_runs": 0}
+
+
+def set_faults(encoder_runs=(), attn_chunks=(), logits_step=None):
+    FAULTS.update(encoder_runs=set(encoder_runs), attn_chunks=set(attn_chunks), logits_step=logits_step)
+    STATE.update(encoder_runs=0, logits_runs=0)
+
+
 class _Session:
     def __init__(self, path, sess_options=None, providers=None):
         self.kind = "encoder" if "encoder" in os.path.basename(path) else "decoder"
@@ -63,11 +74,22 @@ class _Session:
 
     def run(self, names, feeds):
         if self.kind == "encoder":
+            STATE["encoder_runs"] += 1
+            STATE["logits_runs"] = 0
+            if STATE["encoder_runs"] in FAULTS["encoder_runs"]:
+                raise RuntimeError(f"injected encoder failure on run {STATE['encoder_runs']}")
             return [OM.encode(feeds["input_features"])]
         ids = feeds["input_ids"][0].tolist()
         enc = feeds["encoder_hidden_states"]
         names = names or [o.name for o in self.get_outputs()]
         want_attn = any("cross_attentions" in n for n in names)
+        chunk = STATE["encoder_runs"]
+        if want_attn and chunk in FAULTS["attn_chunks"]:
+            raise RuntimeError(f"injected decoder failure (attention outputs) in chunk {chunk}")
+        if not want_attn:
+            STATE["logits_runs"] += 1
+            if FAULTS["logits_step"] == (chunk, STATE["logits_runs"]):
+                raise RuntimeError(f"injected decoder failure at step {STATE['logits_runs']} of chunk {chunk}")
         if want_attn:
             logits, cross = OM.decode_full(ids, enc, want_attn=True)
         else:
@@ -163,6 +185,21 @@ def cases():
         # a model string that IS a key of the alignment-head table but whose mask has another size than layers x heads:
         # no alignment at all, words come back untimed (align.py:81-84, 595-597; core.py:1041-1052)
         "mask_mismatch": dict(model="medium", audio_seed=29, n_samples=16000 * 35, max_tokens=20),
+        # ---- failure isolation (core.py:813-837, 934-980, 1009-1044, 578-597): `faults` goes to set_faults() ----
+        # the encoder run of chunk 2 raises: the chunk is skipped, prefix and audio context start over, chunks 1 and 3 stay
+        "fail_encoder_chunk2_hyphen": dict(audio_seed=41, n_samples=16000 * 75, max_tokens=22, delimiter=" -",
+                                           faults=dict(encoder_runs=[2])),
+        "fail_encoder_chunk2_plain": dict(audio_seed=32, n_samples=16000 * 75, max_tokens=22, faults=dict(encoder_runs=[2])),
+        # every attention-output run of chunk 1 raises: its words come back untimed and only feed the next prefix
+        "fail_alignment_chunk1": dict(audio_seed=33, n_samples=16000 * 63, max_tokens=24, delimiter=" -",
+                                      faults=dict(attn_chunks=[1])),
+        # the 5th decoder run of chunk 2 raises (and so does its alignment): four tokens are kept, words untimed
+        "fail_decode_chunk2_step5": dict(audio_seed=34, n_samples=16000 * 63, max_tokens=24, delimiter=" >",
+                                         faults=dict(logits_step=(2, 5), attn_chunks=[2])),
+        "fail_stream_encoder_chunk2": dict(audio_seed=35, n_samples=16000 * 70, max_tokens=18, delimiter=" -", stream=True,
+                                           faults=dict(encoder_runs=[2])),
+        "fail_forced_window2": dict(audio_seed=36, n_samples=16000 * 47, max_tokens=448,
+                                    transcript=" ".join(f"w{400 + i}" for i in range(24)) + ".", faults=dict(encoder_runs=[2])),
     }
 
 
@@ -179,6 +216,7 @@ def main():
     for name, kw in cases().items():
         kw = dict(kw)
         audio = synth_audio(kw.pop("audio_seed"), kw.pop("n_samples"))
+        set_faults(**kw.pop("faults", {}))
         res = urro_whisper.whisperer(model=kw.pop("model", MODEL), audio=audio, language="en", onnx_encoder=enc_p, onnx_decoder=dec_p,
                                      onnx_providers=["CPUExecutionProvider"], **kw)
         if kw.get("stream"):

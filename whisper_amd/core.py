@@ -123,6 +123,7 @@ class _Run:
             self.ts_end = tokenizer.encode("<|30.00|>", allowed_special="all")[0]
         except Exception as e:
             raise RuntimeError(f"could not encode timestamp end token: {e}")
+        self.owns_engine = engine is None     # an engine built here is closed when the call ends (it holds GBs of HBM)
         if engine is None:
             from .engine import Engine
             name, sd = resolve_weights(model, onnx_encoder, onnx_decoder)
@@ -147,6 +148,11 @@ class _Run:
                 self.user_prompt = [self.sot_prev] + enc
         self.include_timestamps = self.no_timestamps is None or self.no_timestamps not in self.user_prompt
 
+    def close(self) -> None:
+        if self.owns_engine and self.eng is not None:
+            self.eng.close()
+            self.eng = None
+
     def standard_prompt(self) -> List[int]:
         ids = [self.sot]
         try:
@@ -170,28 +176,67 @@ class _Run:
     def is_text(self, t: int) -> bool:
         return t < self.sot and not (self.ts_begin <= t <= self.ts_end)
 
-    # one batch of independent segments -> per segment (new_tokens, text_ids, boundaries)
-    def transcribe(self, segments: Sequence[np.ndarray], prompts: Sequence[List[int]]):
+    # one batch of independent segments -> per segment (new_tokens, text_ids, boundaries, decode_failed), or None
+    def transcribe(self, segments: Sequence[np.ndarray], prompts: Sequence[List[int]], first_chunk: int = 1):
+        """Failure isolation as in the reference's chunk loop: a chunk whose numerics fail is logged and skipped
+        (mel / encoder stage, core.py:813-837) -- its entry is None -- and the chunks before and after it are kept.  A
+        group of windows that fails as a whole is retried window by window, so one bad window costs only itself.  A
+        window whose decoder produced a non-finite logits row comes back with the tokens generated before that step
+        and decode_failed set (the reference's generation-loop failure, core.py:934-980: error stored, partial tokens
+        kept)."""
         eng = self.eng
         submit = getattr(eng, "transcribe_windows_async", None)   # an EnginePool keeps several groups in flight
-        pending = []
-        for i0 in range(0, len(segments), eng.max_batch):
-            segs, prs = segments[i0:i0 + eng.max_batch], prompts[i0:i0 + eng.max_batch]
+
+        def call_args(segs, prs):
             stride = max(len(s) for s in segs)
             buf = np.zeros((len(segs), stride), dtype=np.float32)
             for i, s in enumerate(segs):
                 buf[i, :len(s)] = s
             n = torch.tensor([len(s) for s in segs], dtype=torch.int32)
-            args = (torch.from_numpy(buf).to(eng.device), n, prs, self.max_tokens, self.eot, self.sot, self.ts_begin, self.ts_end)
-            pending.append((len(segs), submit(*args) if submit else eng.transcribe_windows(*args)))
-        out = []
-        for count, res in pending:
-            if submit:
-                res = res.result()
+            return (torch.from_numpy(buf).to(eng.device), n, list(prs), self.max_tokens, self.eot, self.sot, self.ts_begin, self.ts_end)
+
+        def unpack(res, count, chunk0):
             n_new, n_text = res["n_new"].cpu().numpy(), res["n_text"].cpu().numpy()
             new, text, bnd = res["new_tokens"].cpu().numpy(), res["text_ids"].cpu().numpy(), res["boundaries"].cpu().numpy()
+            status = res.get("status")
+            status = np.zeros(count, dtype=np.int32) if status is None else np.asarray(status.cpu() if hasattr(status, "cpu") else status)
+            out = []
             for i in range(count):
-                out.append((new[i, :n_new[i]].tolist(), text[i, :n_text[i]].tolist(), bnd[i, :n_text[i] + 1].tolist()))
+                if status[i]:
+                    logger.error(f"error during decoder generation loop for chunk {chunk0 + i}: non-finite logits after "
+                                 f"{int(n_new[i])} generated tokens")
+                out.append((new[i, :n_new[i]].tolist(), text[i, :n_text[i]].tolist(), bnd[i, :n_text[i] + 1].tolist(), bool(status[i])))
+            return out
+
+        pending = []
+        for i0 in range(0, len(segments), eng.max_batch):
+            segs, prs = segments[i0:i0 + eng.max_batch], prompts[i0:i0 + eng.max_batch]
+            try:
+                args = call_args(segs, prs)
+                pending.append((i0, segs, prs, submit(*args) if submit else eng.transcribe_windows(*args), None))
+            except Exception as e:                      # noqa: BLE001 -- the reference catches broadly and skips the chunk
+                pending.append((i0, segs, prs, None, e))
+        out = []
+        for i0, segs, prs, res, err in pending:
+            if err is None:
+                try:
+                    if submit:
+                        res = res.result()
+                    out += unpack(res, len(segs), first_chunk + i0)
+                    continue
+                except Exception as e:                  # noqa: BLE001
+                    err = e
+            if len(segs) == 1:
+                logger.error(f"chunk {first_chunk + i0} failed on the engine and is skipped: {err}")
+                out.append(None)
+                continue
+            logger.error(f"a group of {len(segs)} chunks starting at chunk {first_chunk + i0} failed ({err}); retrying them one by one")
+            for i, (seg, pr) in enumerate(zip(segs, prs)):
+                try:
+                    out += unpack(eng.transcribe_windows(*call_args([seg], [pr])), 1, first_chunk + i0 + i)
+                except Exception as e:                  # noqa: BLE001
+                    logger.error(f"chunk {first_chunk + i0 + i} failed on the engine and is skipped: {e}")
+                    out.append(None)
         return out
 
     def words_for(self, text_ids, boundaries, start_sample, context_dur):
@@ -219,11 +264,14 @@ def whisperer(model: str, audio: Union[str, np.ndarray], language: str = "en", t
     if diarization and not big_model:
         logger.warning("speaker diarization with `speaker()` and `person()` is only supported by model sizes medium, "
                        "large-v1, large-v2, and large-v3")
-    if transcript is not None:
-        return _align_transcript(run, audio_data, transcript)
     if stream:
-        return _stream(run, audio_data, delimiter, diarization)
-    return _transcribe(run, audio_data, delimiter, diarization, big_model)
+        return _stream(run, audio_data, delimiter, diarization)     # the generator closes the run when it ends
+    try:
+        if transcript is not None:
+            return _align_transcript(run, audio_data, transcript)
+        return _transcribe(run, audio_data, delimiter, diarization, big_model)
+    finally:
+        run.close()
 
 
 def _align_transcript(run: _Run, audio: np.ndarray, transcript: str) -> Dict:
@@ -243,32 +291,53 @@ def _align_transcript(run: _Run, audio: np.ndarray, transcript: str) -> Dict:
         return e.align(torch.tensor([len(t) for t in texts_live], dtype=torch.int32)).cpu().numpy()
 
     submit = getattr(eng, "submit", None)      # an EnginePool keeps several groups in flight
+
+    def group_args(group, texts, live):
+        stride = max(group[k][1] - group[k][0] for k in live)
+        buf = np.zeros((len(live), stride), dtype=np.float32)
+        for r, k in enumerate(live):
+            seg = audio[group[k][0]:group[k][1]]
+            buf[r, :len(seg)] = seg
+        n = torch.tensor([group[k][1] - group[k][0] for k in live], dtype=torch.int32)
+        return (torch.from_numpy(buf), n, [prompt] * len(live), [texts[k] for k in live])
+
     pending = []
     for i0 in range(0, len(windows), eng.max_batch):
         group = windows[i0:i0 + eng.max_batch]
         texts = [[t for t in tokens[w[2]:w[3]] if run.is_text(t)] for w in group]
         # no alignment heads (unknown model key / mask of another size): every window comes back empty (align.py:595-597)
         live = [k for k, t in enumerate(texts) if t and eng.heads and len(prompt) + len(t) - 1 <= eng.n_text_ctx]
-        bnd = None
+        bnd, err = None, None
         if live:
-            stride = max(group[k][1] - group[k][0] for k in live)
-            buf = np.zeros((len(live), stride), dtype=np.float32)
-            for r, k in enumerate(live):
-                seg = audio[group[k][0]:group[k][1]]
-                buf[r, :len(seg)] = seg
-            n = torch.tensor([group[k][1] - group[k][0] for k in live], dtype=torch.int32)
-            args = (torch.from_numpy(buf), n, [prompt] * len(live), [texts[k] for k in live])
-            bnd = submit(boundaries_of, *args) if submit else boundaries_of(eng, *args)
-        pending.append((group, texts, live, bnd))
+            try:
+                args = group_args(group, texts, live)
+                bnd = submit(boundaries_of, *args) if submit else boundaries_of(eng, *args)
+            except Exception as e:                      # noqa: BLE001 -- a failing window yields no words (core.py:578-597,691-693)
+                err = e
+        pending.append((i0, group, texts, live, bnd, err))
     results: List[List[Dict]] = []
-    for group, texts, live, bnd in pending:
+    for i0, group, texts, live, bnd, err in pending:
         group_words: List[List[Dict]] = [[] for _ in group]
-        if live:
-            if submit:
-                bnd = bnd.result()
-            for r, k in enumerate(live):
-                if bnd[r, 0] >= 0:     # -1: DTW found no path for this window (align.py:823-827)
-                    group_words[k] = run.words_for(texts[k], bnd[r, :len(texts[k]) + 1].tolist(), group[k][0], 0.0)
+        rows = {}                                       # window index in the group -> its boundary row
+        if live and err is None:
+            try:
+                if submit:
+                    bnd = bnd.result()
+                rows = {k: bnd[r] for r, k in enumerate(live)}
+            except Exception as e:                      # noqa: BLE001
+                err = e
+        if live and err is not None:
+            logger.error(f"alignment of windows {i0 + 1}..{i0 + len(group)} failed as a group ({err}); retrying them one by one")
+            for k in live:
+                try:
+                    one_args = group_args(group, texts, [k])
+                    one = submit(boundaries_of, *one_args).result() if submit else boundaries_of(eng, *one_args)
+                    rows[k] = one[0]
+                except Exception as e:                  # noqa: BLE001
+                    logger.error(f"window {i0 + k + 1}: alignment failed: {e}")
+        for k, row in rows.items():
+            if row[0] >= 0:     # -1: DTW found no path for this window (align.py:823-827)
+                group_words[k] = run.words_for(texts[k], row[:len(texts[k]) + 1].tolist(), group[k][0], 0.0)
         results += group_words
     words = A.merge_overlapping_alignment_results(results, windows)
     return {"text": transcript, "words": words, "tokens": tokens, "language": run.language}
@@ -288,13 +357,25 @@ def _chunks(total: int, chunk_size: int):
 def _stream(run: _Run, audio: np.ndarray, delimiter, diarization) -> Generator[str, None, None]:
     """Generator mode (core.py:238-536): decoded text per generated text token, text-only prefix carry-over."""
     def gen():
-        prefix = delimiter
+        try:
+            yield from chunks()
+        finally:
+            run.close()
+
+    def chunks():
+        prefix, idx = delimiter, 0
         for start, end in _chunks(len(audio), CHUNK_LENGTH_SAMPLES):
             seg = audio[start:end]
             if len(seg) < MIN_CHUNK_SAMPLES:
                 prefix = delimiter
+                idx += 1
                 continue
-            new, text, _ = run.transcribe([seg], [run.chunk_prompt(prefix)])[0]
+            idx += 1
+            got = run.transcribe([seg], [run.chunk_prompt(prefix)], first_chunk=idx)[0]
+            if got is None:                      # mel / encoder stage failed: skip the chunk, reset the prefix (core.py:286-312)
+                prefix = delimiter
+                continue
+            new, text = got[0], got[1]
             for t in new:
                 if run.is_text(t):
                     piece = run.tok.decode([t])
@@ -330,8 +411,9 @@ def _transcribe(run: _Run, audio: np.ndarray, delimiter, diarization, big_model)
         spans = [(s, e) for s, e in _chunks(total, chunk_size) if e - s >= MIN_CHUNK_SAMPLES]
         prompt_ids = run.chunk_prompt(None)
         outs = run.transcribe([audio[s:e] for s, e in spans], [prompt_ids] * len(spans)) if spans else []
-        for (s, e), (new, text, bnd) in zip(spans, outs):
-            finish(new, text, bnd, s, 0.0)
+        for (s, e), got in zip(spans, outs):
+            if got is not None:                  # a failed chunk contributes nothing (core.py:813-837)
+                finish(got[0], got[1], got[2], s, 0.0)
     else:
         offset, idx = 0, 0
         prefix, context = delimiter, np.zeros(0, np.float32)
@@ -350,8 +432,12 @@ def _transcribe(run: _Run, audio: np.ndarray, delimiter, diarization, big_model)
             if len(seg) < MIN_CHUNK_SAMPLES:
                 offset, context, prefix = end, np.zeros(0, np.float32), delimiter
                 continue
-            new, text, bnd = run.transcribe([seg], [run.chunk_prompt(prefix)])[0]
-            words = finish(new, text, bnd, start, context_dur)
+            got = run.transcribe([seg], [run.chunk_prompt(prefix)], first_chunk=idx)[0]
+            if got is None:
+                # mel / encoder stage failed: the chunk is skipped, context and prefix start over (core.py:813-837)
+                offset, context, prefix = end, np.zeros(0, np.float32), delimiter
+                continue
+            words = finish(got[0], got[1], got[2], start, context_dur)
             context = np.zeros(0, np.float32)
             if words:
                 prefix = _next_prefix(words, delimiter, diarization)

@@ -302,6 +302,15 @@ int uw_dtw_static_run(const double* cost, const int32_t* n_tok, int B, int n_row
     int dev = 0;
     UW_HIP_CHECK(hipGetDevice(&dev));
     UW_REQUIRE(dev >= 0 && dev < 64, "uw_dtw_static: device ordinal %d out of range", dev);
+    // the array used is the CURRENT device's copy: the kernel must run there too, i.e. the caller's buffers (and the
+    // stream they are used on) must belong to the current device
+    hipPointerAttribute_t at;
+    if (cost && hipPointerGetAttributes(&at, cost) == hipSuccess) {
+        UW_REQUIRE(at.device == dev, "uw_dtw_static: the cost matrix lives on device %d but device %d is current; make the "
+                                     "buffers' device current before the call", at.device, dev);
+    } else {
+        (void)hipGetLastError();   // not a pointer the runtime knows: let the kernel launch report it
+    }
     void* ptr = dev_ptr[dev].load(std::memory_order_acquire);
     if (!ptr) {
         UW_HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));

@@ -79,7 +79,8 @@ struct uw_ctx {
     uint8_t* dtw_ws = nullptr;
     int32_t *st_tokens = nullptr, *st_pos = nullptr, *st_n_new = nullptr, *st_n_text = nullptr, *st_active = nullptr,
             *st_dirty = nullptr, *st_max_new = nullptr, *st_n_active = nullptr, *st_text = nullptr, *st_next = nullptr,
-            *st_qfirst = nullptr, *st_qcount = nullptr, *st_zero = nullptr, *st_ids = nullptr;
+            *st_qfirst = nullptr, *st_qcount = nullptr, *st_zero = nullptr, *st_ids = nullptr, *st_failed = nullptr;
+    std::vector<int32_t> window_status;   // host copy of st_failed after the last greedy decode
     int32_t* host_pin = nullptr;   // pinned scratch for small read-backs
     int cross_batch = 0;           // windows covered by the current cross K/V
     int step_rows = 0;             // upper bound of (position + 1) of the next decode step over its windows (0: unknown)
@@ -387,7 +388,7 @@ int alloc_workspace(uw_ctx* c)
     ALLOC(c->st_text, Bm * Tm * 4, true);
     ALLOC(c->st_ids, Bm * Tm * 4, true);
     int32_t** small[] = {&c->st_pos, &c->st_n_new, &c->st_n_text, &c->st_active, &c->st_dirty, &c->st_max_new,
-                         &c->st_n_active, &c->st_next, &c->st_qfirst, &c->st_qcount, &c->st_zero};
+                         &c->st_n_active, &c->st_next, &c->st_qfirst, &c->st_qcount, &c->st_zero, &c->st_failed};
     for (auto pp : small) ALLOC(*pp, (Bm + 8) * 4, true);
     UW_HIP_CHECK(hipHostMalloc((void**)&c->host_pin, (size_t)(8 * Bm + 64) * 4, hipHostMallocDefault));
     return UW_OK;
@@ -767,6 +768,7 @@ __global__ void greedy_init_kernel(GreedyState st, const int32_t* __restrict__ p
         st.n_new[b] = 0;
         st.n_text[b] = 0;
         st.dirty_from[b] = -1;
+        st.failed[b] = 0;
         st.max_new[b] = budget;
         st.active[b] = budget > 0 ? 1 : 0;
     }
@@ -822,7 +824,7 @@ GreedyState state_of(uw_ctx* c)
     GreedyState st;
     st.tokens = c->st_tokens; st.ld_tok = c->Tm; st.pos = c->st_pos; st.n_new = c->st_n_new; st.n_text = c->st_n_text;
     st.active = c->st_active; st.dirty_from = c->st_dirty; st.max_new = c->st_max_new; st.n_active = c->st_n_active;
-    st.text_ids = c->st_text;
+    st.text_ids = c->st_text; st.failed = c->st_failed;
     return st;
 }
 
@@ -1097,7 +1099,7 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
                 const int b0 = sub_b0[k], Bn = sub_b0[k + 1] - sub_b0[k];
                 GreedyState sk = st;
                 sk.tokens += (long)b0 * st.ld_tok; sk.text_ids += (long)b0 * st.ld_tok;
-                sk.pos += b0; sk.n_new += b0; sk.n_text += b0; sk.active += b0; sk.dirty_from += b0; sk.max_new += b0;
+                sk.pos += b0; sk.n_new += b0; sk.n_text += b0; sk.active += b0; sk.dirty_from += b0; sk.max_new += b0; sk.failed += b0;
                 sk.n_active = c->st_n_active + k;
                 c->step_rows = std::min(c->Tm, Pmax + step);   // the longest prompt's position + 1 at this step
                 RUN(decoder_step(c, b0, Bn, step == 0, ss[k]));
@@ -1124,7 +1126,10 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
     int32_t *h_ntext = c->host_pin, *h_dirty = c->host_pin + c->Bm, *h_need = c->host_pin + 2 * c->Bm;
     UW_HIP_CHECK(hipMemcpyAsync(h_ntext, c->st_n_text, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     UW_HIP_CHECK(hipMemcpyAsync(h_dirty, c->st_dirty, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    int32_t* h_failed = c->host_pin + 6 * c->Bm + 16;   // clear of h_active ([4 Bm, 4 Bm + 4)) for every Bm
+    UW_HIP_CHECK(hipMemcpyAsync(h_failed, c->st_failed, (size_t)B * 4, hipMemcpyDeviceToHost, s));
     UW_HIP_CHECK(hipStreamSynchronize(s));
+    c->window_status.assign(h_failed, h_failed + B);
     int T_forced = 0;
     for (int b = 0; b < B; ++b) {
         h_need[b] = (h_dirty[b] >= 0 && h_ntext[b] > h_dirty[b]) ? 1 : 0;
@@ -1137,6 +1142,15 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
     hipLaunchKernelGGL(copy_tokens_out_kernel, dim3(B), dim3(256), 0, s, st, plen_dev, new_tokens, n_new, text_ids, n_text, c->Tm);
     UW_LAUNCH_CHECK();
     UW_HIP_CHECK(hipStreamSynchronize(s));
+    return UW_OK;
+}
+
+int uw_window_status(uw_ctx* c, int B, int32_t* status_host)
+{
+    UW_REQUIRE(c && status_host && B > 0, "uw_window_status: bad arguments");
+    UW_REQUIRE((size_t)B <= c->window_status.size(), "uw_window_status: the last greedy decode covered %d windows, %d asked for",
+               (int)c->window_status.size(), B);
+    memcpy(status_host, c->window_status.data(), (size_t)B * 4);
     return UW_OK;
 }
 

@@ -73,11 +73,34 @@ __device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsi
                  : "memory");
 }
 
+// Six of them in one statement (M0 saved once): the pieces of one ring stage of a four-wave tile kernel -- four of operand
+// A and two of operand B, each from its own wave-uniform base with per-lane offsets, into consecutive 4 KiB slabs.
+__device__ __forceinline__ void glds16_sv_4a2b(const void* abase, const unsigned (&aoff)[4], unsigned a_lds, const void* bbase,
+                                               const unsigned (&boff)[2], unsigned b_lds)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %9\n\t"
+                 "s_add_u32 m0, %7, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %9\n\t"
+                 "s_add_u32 m0, %7, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %9\n\t"
+                 "s_add_u32 m0, %7, 0x3000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %9\n\t"
+                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %10\n\t"
+                 "s_add_u32 m0, %8, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %10\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "v"(aoff[3]), "v"(boff[0]), "v"(boff[1]), "s"(a_lds), "s"(b_lds), "s"(abase),
+                   "s"(bbase)
+                 : "memory", "scc");
+}
+
 // s_waitcnt vmcnt(0) that the COMPILER sees (expcnt and lgkmcnt left alone).  Ordinary loads issued before a loop
 // whose first use is inside the loop make hipcc place a vmcnt wait at that use in every iteration -- and since it
 // does not count the asm-issued LDS DMAs, that wait is vmcnt(0) and drains the ring each time round.  Retiring
 // such loads with this builtin in front of the loop removes the in-loop waits.
 __device__ __forceinline__ void retire_vector_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+// s_waitcnt lgkmcnt(0), likewise visible to the compiler: fragments read from LDS one loop iteration ahead are then known
+// to be in their registers, so no wait is inserted in front of the instructions that use them.
+__device__ __forceinline__ void retire_lds_reads() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  This bijection hands each
 // XCD a CONTIGUOUS run of tile indices, so tiles that share an operand panel hit the same L2 (speed only).
@@ -182,14 +205,16 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// First index of the maximum of row[0..V) (numpy argmax tie rule; NaN never wins, inputs are finite logits), computed by
-// a 1024-thread workgroup: 16-byte loads, eight independent loads in flight per thread.  sv / si: 16-entry LDS scratch.
-// The result is valid in thread 0 (after the internal barrier); row must be 16-byte aligned for the vector path.
-__device__ __forceinline__ int block_argmax_1024(const float* __restrict__ row, int V, float* sv, int* si)
+// First index of the maximum of row[0..V) (numpy argmax tie rule), computed by a 1024-thread workgroup: 16-byte loads,
+// eight independent loads in flight per thread.  sv / si: 16-entry LDS scratch.  The result is valid in thread 0 (after
+// the internal barrier); row must be 16-byte aligned for the vector path.  A NaN never wins the comparison; *any_nan
+// (valid in every thread) tells the caller that the row held one, so it can refuse the row instead of trusting the index.
+__device__ __forceinline__ int block_argmax_1024(const float* __restrict__ row, int V, float* sv, int* si, bool* any_nan = nullptr)
 {
     float best = -INFINITY;
     int arg = 0x7fffffff;
-    auto take = [&](float v, int i) { if (v > best || (v == best && i < arg)) { best = v; arg = i; } };
+    bool bad = false;
+    auto take = [&](float v, int i) { bad |= (v != v); if (v > best || (v == best && i < arg)) { best = v; arg = i; } };
     const bool vec = (((uintptr_t)row & 15) == 0);
     const int V4 = vec ? (V >> 2) : 0;
     for (int i0 = threadIdx.x; i0 < V4; i0 += 8192) {
@@ -212,7 +237,8 @@ __device__ __forceinline__ int block_argmax_1024(const float* __restrict__ row, 
         if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }
     }
     if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = arg; }
-    __syncthreads();
+    const int nan_seen = __syncthreads_or(bad ? 1 : 0);
+    if (any_nan) *any_nan = nan_seen != 0;
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < arg)) { best = sv[w]; arg = si[w]; }

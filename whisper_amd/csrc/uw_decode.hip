@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
 #pragma unroll
     for (int e = 0; e < R::E; ++e) q[e] = to_f32<T>(qkv[e]);
     const int n = pos + 1;
-    constexpr int U = NU > 0 ? NU : 4;
+    constexpr int U = NU > 0 ? NU : (sizeof(T) == 2 ? 8 : 4);   // loads in flight per lane (the cross kernel keeps 8 as well)
     const int rows_per_round = 4 * R::RPI * U;
     // NU > 0: one round covers max_rows rows; a window beyond the launcher's bound (never in the greedy loop, whose
     // bound is exact) simply takes further rounds
@@ -412,14 +412,13 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
             if (sub == 0 && r < n) sc[r] = s;
         }
     }
-    const bool one_round = NU > 0 && n <= rows_per_round;   // block-uniform
-    if (one_round) {
+    // the first round of V rows is requested now, so the memory system stays busy while the workgroup does its softmax
+    // (with NU > 0 and a window inside the launcher's bound it is the only round)
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = (u * 4 + wave) * R::RPI + rin;
-            vv[u] = vnew;
-            if (r < pos) vv[u] = ld_stream(Vc + (long)r * ld);
-        }
+    for (int u = 0; u < U; ++u) {
+        const int r = (u * 4 + wave) * R::RPI + rin;
+        vv[u] = vnew;
+        if (r < pos) vv[u] = ld_stream(Vc + (long)r * ld);
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -442,7 +441,7 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
 #pragma unroll
     for (int e = 0; e < R::E; ++e) acc[e] = 0.f;
     for (int r0 = 0; r0 < n; r0 += rows_per_round) {
-        if (!one_round) {
+        if (r0 > 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int r = r0 + (u * 4 + wave) * R::RPI + rin;
@@ -491,11 +490,17 @@ __global__ __launch_bounds__(1024) void greedy_next_kernel(GreedyState st, const
     __shared__ int s_next[2];
     const int b = blockIdx.x;
     if (!st.active[b]) return;
-    const int tok = block_argmax_1024(logits + (long)b * ld, V, sv, si);
+    bool nan_row = false;
+    const int tok = block_argmax_1024(logits + (long)b * ld, V, sv, si, &nan_row);
     if (threadIdx.x == 0) {
         bool alive = true;
         int idx = -1;
-        if (tok == eot) {
+        if (nan_row) {
+            // np.argmax would return the NaN's index and the reference would go on decoding garbage; here the window
+            // stops like a decoder run that raised (core.py:978-980): the tokens generated so far are kept
+            alive = false;
+            if (st.failed) st.failed[b] = 1;
+        } else if (tok == eot) {
             alive = false;
         } else {
             idx = st.pos[b] + 1;   // pos = index of the token that produced these logits

@@ -40,6 +40,7 @@ struct GemmParams {
     // instead of sixteen half lines, which nearly doubles what a CU takes in.  kstep_x = R * KT (elements between
     // K-steps) with ldx = KT marks operand x as K-blocked; c_kblock = rows of C writes the output in the same form.
     long kstep_a = 0, kstep_b = 0, c_kblock = 0;
+    int panel_n = 0;   // set by the launcher: column tiles per panel of the panel tile order (0: plain order)
     // second, TRANSPOSED copy of the output columns n >= c2_col0 (two-workgroup tile kernel, compute-dtype output):
     // C2[(n - c2_col0) * ldc2 + m], batch item b at C2 + b * sC2 -- V^T beside the head-contiguous K|V of a projection
     void* C2 = nullptr;
@@ -171,6 +172,7 @@ struct GreedyState {
     int32_t* max_new = nullptr;    // [B]
     int32_t* n_active = nullptr;   // [1] windows still decoding
     int32_t* text_ids = nullptr;   // [B][ld_tok] generated text tokens
+    int32_t* failed = nullptr;     // [B] 1: decoding stopped at a logits row that held a NaN (tokens before it are kept)
 };
 // end of a greedy step: argmax of logits[b][0..V) per window, append / stop on eot / budget, classify text tokens,
 // advance pos, and write the chosen token's embedding as row b of the next step's residual stream x (x layout)

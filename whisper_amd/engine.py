@@ -165,7 +165,14 @@ class Engine:
         L.check(self.lib.uw_decode_greedy(self.ctx, L.ptr(ids), ld, lens.ctypes.data_as(C.POINTER(C.c_int32)), B,
                                           int(max_tokens), int(eot), int(sot), int(ts_begin), int(ts_end),
                                           L.ptr(new_tokens), L.ptr(n_new), L.ptr(text_ids), L.ptr(n_text), self._s()))
-        return {"new_tokens": new_tokens, "n_new": n_new, "text_ids": text_ids, "n_text": n_text}
+        return {"new_tokens": new_tokens, "n_new": n_new, "text_ids": text_ids, "n_text": n_text, "status": self.window_status(B)}
+
+    def window_status(self, B: int) -> torch.Tensor:
+        """Per window of the last greedy decode: 0 = decoded normally, 1 = stopped at a non-finite logits row with the
+        tokens before it kept (the reference's decoder-run failure inside its generation loop, core.py:948-980)."""
+        out = np.zeros((B,), dtype=np.int32)
+        L.check(self.lib.uw_window_status(self.ctx, B, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return torch.from_numpy(out)          # host tensor: the library hands the flags over on the host
 
     def attn_rows_forced(self, prompts: Sequence[Sequence[int]], texts: Sequence[Sequence[int]]) -> None:
         B = len(prompts)
@@ -204,7 +211,8 @@ class Engine:
             self.ctx, L.ptr(audio), stride, L.ptr(n_samples), L.ptr(ids), ld, lens.ctypes.data_as(C.POINTER(C.c_int32)),
             B, int(max_tokens), int(eot), int(sot), int(ts_begin), int(ts_end), L.ptr(new_tokens), L.ptr(n_new),
             L.ptr(text_ids), L.ptr(n_text), L.ptr(bounds), self._s()))
-        return {"new_tokens": new_tokens, "n_new": n_new, "text_ids": text_ids, "n_text": n_text, "boundaries": bounds}
+        return {"new_tokens": new_tokens, "n_new": n_new, "text_ids": text_ids, "n_text": n_text, "boundaries": bounds,
+                "status": self.window_status(B)}
 
 
 # ---- context-free alignment kernels ----------------------------------------------------------------

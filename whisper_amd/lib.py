@@ -46,6 +46,7 @@ SIGNATURES = {
     "uw_decode_step": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
     "uw_decode_greedy": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i32), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "uw_window_status": (C.c_int, [_vp, C.c_int, C.POINTER(_i32)]),
     "uw_attn_rows_forced": (C.c_int, [_vp, _vp, C.c_int, C.POINTER(_i32), _vp, C.c_int, C.POINTER(_i32), C.c_int, _vp]),
     "uw_get_attn_rows": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "uw_cost_matrix": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),

@@ -25,17 +25,10 @@ AVAILABLE_PROVIDERS = [PROVIDER]
 
 def resolve_weights(model: str, encoder_path: Optional[str] = None, decoder_path: Optional[str] = None
                     ) -> Tuple[str, Dict[str, torch.Tensor]]:
-    """-> (shape name, fp32 state dict)."""
-    if encoder_path and decoder_path and encoder_path.endswith(".onnx") and decoder_path.endswith(".onnx"):
-        # the reference's rule: user paths are used only if BOTH files exist (download.py:229-237)
-        if not (os.path.isfile(encoder_path) and os.path.isfile(decoder_path)):
-            raise FileNotFoundError(f"onnx files not found: '{encoder_path}', '{decoder_path}' (downloading is not available)")
-        from ..weights import check_state_dict
-        from .onnx_weights import load_onnx_pair
-        sd = load_onnx_pair(encoder_path, decoder_path)
-        name = model if model and not model.endswith(".onnx") else os.path.basename(os.path.dirname(os.path.abspath(encoder_path)))
-        check_state_dict(dims_for(name), sd)
-        return name, sd
+    """-> (shape name, fp32 state dict).  Sources, in this order: "synthetic:<shape>" (deterministic generator); a
+    directory of HF-layout *.safetensors files; the reference's own file pair -- the user's `onnx_encoder` /
+    `onnx_decoder` when both exist, else the files the reference keeps under ~/.cache/urro_whisper/models/<name>/
+    (download.py:217-259; nothing is downloaded here)."""
     src = encoder_path or model
     if isinstance(src, str) and src.startswith("synthetic:"):
         name = src.split(":", 1)[1]
@@ -43,8 +36,27 @@ def resolve_weights(model: str, encoder_path: Optional[str] = None, decoder_path
     if isinstance(src, str) and os.path.isdir(src):
         name = model if not os.path.isdir(model) else os.path.basename(os.path.normpath(model))
         return name, load_safetensors_dir(src)
-    raise FileNotFoundError(f"no weights found for model '{model}': expected a .safetensors directory or 'synthetic:<shape>' "
-                            "(downloading is not available)")
+    from ..weights import check_state_dict
+    from .download import SIZE_ALIASES, get_onnx_model_paths
+    from .onnx_weights import load_onnx_pair
+    enc_file, dec_file = get_onnx_model_paths(model, encoder_path, decoder_path)      # raises FileNotFoundError
+    sd = load_onnx_pair(enc_file, dec_file)
+    if model and not model.endswith(".onnx"):
+        name = SIZE_ALIASES.get(model.lower(), model)
+    else:
+        name = os.path.basename(os.path.dirname(os.path.abspath(enc_file)))
+    check_state_dict(dims_for(name), sd)
+    return name, sd
+
+
+def decoder_file_for(model: str, encoder_path: Optional[str] = None, decoder_path: Optional[str] = None) -> Optional[str]:
+    """The decoder file resolve_weights would read (None for synthetic / safetensors sources): its name says whether
+    the session should look like the merged export."""
+    src = encoder_path or model
+    if isinstance(src, str) and (src.startswith("synthetic:") or os.path.isdir(src)):
+        return None
+    from .download import get_onnx_model_paths
+    return get_onnx_model_paths(model, encoder_path, decoder_path)[1]
 
 
 def select_providers(onnx_providers: Optional[List[str]], exclude_providers: Optional[List[str]]) -> List[str]:
@@ -75,7 +87,8 @@ def load_onnx_models(encoder_path, decoder_path, onnx_providers=None, verbose=Fa
     heads = alignment_heads(alignment_heads_key(name, dims.d_model, language), dims.dec_layers, dims.n_heads) or []
     eng = Engine(dims, sd, dtype=dtype, max_batch=max_batch, align_heads=heads)
     # decoder_model_merged.onnx (what the reference prefers, download.py:259) declares the cache inputs; mirror that
-    merged = isinstance(decoder_path, str) and "merged" in os.path.basename(decoder_path)
+    dec_file = decoder_file_for(model or encoder_path, encoder_path, decoder_path) or decoder_path
+    merged = isinstance(dec_file, str) and "merged" in os.path.basename(dec_file)
     enc, dec = EncoderSession(eng), DecoderSession(eng, merged=merged)
     logger.info(f"models loaded using {enc.get_providers()} for encoder and {dec.get_providers()} for decoder")
     return enc, dec

@@ -92,11 +92,16 @@ class DecoderSession:
 
     def _ensure_cross_kv(self, enc: np.ndarray) -> None:
         # The reference passes the same encoder states on every step of a chunk, as a fresh astype() copy each time
-        # (core.py:942): project them once per content, recognised by a hash of a strided sample (a few hundred
-        # values spread over the whole array) plus the shape -- not by address, and without reading every element.
+        # (core.py:942): project them once per content, recognised by the shape, a hash of a strided sample (a few hundred
+        # values spread over the whole array) and a hash of coarse block sums -- not by address.
         flat = enc.reshape(-1)
         stride = max(1, flat.size // 509)
-        key = (enc.shape, hash(flat[::stride].tobytes()), float(flat[0]), float(flat[-1]))
+        # ... plus one pass of coarse sums over the whole array (64 values each), so that a caller who patches or zeroes
+        # a region between two runs does not get the previous projection back
+        n64 = flat.size // 64 * 64
+        coarse = flat[:n64].reshape(-1, 64).sum(axis=1, dtype=np.float64)
+        key = (enc.shape, hash(flat[::stride].tobytes()), hash(coarse.tobytes()), float(flat[n64:].sum(dtype=np.float64)),
+               float(flat[0]), float(flat[-1]))
         if key != self._enc_key:
             self.engine.cross_kv(enc.shape[0], torch.from_numpy(enc).to(self.engine.device))
             self._enc_key = key
