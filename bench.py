@@ -367,6 +367,23 @@ def main():
         secondary.append({"kernel": "dtw_kernel", "bound": "dependency chain", "achieved": b / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                           "unit": "GB/s", "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": ms,
                           "us_per_antidiagonal": 1e3 * ms / (n_rows + 1499) if n_rows else None})
+    # one whole decode step (all its launches), sampled one step in eight: its bytes are the decoder weights once, plus per
+    # window the cross K/V of every layer and the self K/V cache read so far
+    Ld, V = dims.dec_layers, dims.vocab
+    w_dec = (Ld * 14 * d * d + V * d) * es
+    kv_cross_step = windows_per_launch * Ld * 2 * 1500 * d * es
+    sp = prof["decode_step"]
+    step_ms = sp["timed_ms"] / sp["timed"] if sp["timed"] else None
+    self_us = (1e3 * prof["self_decode"]["timed_ms"] / prof["self_decode"]["timed"]) if prof["self_decode"]["timed"] else 0.0
+    if step_ms:
+        kv_self_step = windows_per_launch * Ld * 2 * d * es * (P + (float(n_new.mean()) - 1) / 2)
+        sb = w_dec + kv_cross_step + kv_self_step
+        gemm_ms = max(1e-6, step_ms - Ld * (avg_ms + self_us * 1e-3))       # what is left of a step beside its attention kernels
+        secondary.append({"kernel": "decode step (all launches of one greedy step)", "bound": "hbm", "achieved": sb / (step_ms * 1e-3) / 1e9,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": step_ms,
+                          "bytes_per_step": sb, "weight_bytes_per_step": w_dec, "steps_timed": sp["timed"],
+                          "weight_products_ms": gemm_ms, "launches_per_step": 7 * Ld + 2,
+                          "weight_products_achieved_GBs": w_dec / (gemm_ms * 1e-3) / 1e9})
     model_ms = path_roofline_ms(dims, B, P, args.gen, es)
     solo_ms = 1e3 * solo_elapsed / solo_steps
     ov_ms = prof_ov["timed_ms"] / max(1, prof_ov["timed"])
@@ -374,8 +391,26 @@ def main():
                   "frac": bytes_per_launch / (ov_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ov_ms > 0 else 0.0,
                   "launches_timed": prof_ov["timed"],
                   "note": f"same kernel inside the headline region ({args.inflight} batches in flight share the GPU)"}
+    # the dominant kernel by bytes per decode step: the cross-attention K/V stream when the batch is large, the decoder's
+    # weight products (read once per step whatever the batch) when it is small or the model wide
+    if kv_cross_step >= w_dec or not step_ms:
+        dominant = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "kernel": "cross_decode_kernel", "bytes_per_launch": bytes_per_launch,
+                    "windows_per_launch": windows_per_launch, "avg_launch_ms": avg_ms, "launches_timed": prof["timed"],
+                    "launches": prof["launches"]}
+    else:
+        gemm_ms = max(1e-6, step_ms - Ld * (avg_ms + self_us * 1e-3))
+        a = w_dec / (gemm_ms * 1e-3) / 1e9
+        dominant = {"bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "decode-step weight products (gemm_step_ln_kernel + gemm_skinny_kernel + gemm_rows_hilo_kernel)",
+                    "bytes_per_launch": w_dec, "launch": f"the {7 * Ld + 1} weight products of one decode step, taken together",
+                    "avg_launch_ms": gemm_ms, "launches_timed": sp["timed"],
+                    "note": "the decoder weights (read once per step) outweigh the cross K/V of this batch: duration = a whole decode "
+                            "step (HIP events, one step in eight) minus its attention decode launches (timed separately)",
+                    "cross_decode_kernel": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "avg_launch_ms": avg_ms,
+                                            "bytes_per_launch": bytes_per_launch}}
     line = {
-        "metric": "audio-sec/sec (RTFx) whole node, whisper-small greedy + word timestamps",
+        "metric": f"audio-sec/sec (RTFx) whole node, whisper-{args.model} greedy + word timestamps",
         "value": value, "unit": "audio-sec/sec", "n_gpus": world,
         "ranks_seen": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
@@ -385,14 +420,11 @@ def main():
                                f"{args.gen} tokens per window with alignment-head capture, median-filter + DTW word alignment",
                    "global_batch": n_global, "windows_per_gpu": B, "batches_in_flight": args.inflight, "prompt_len": P, "generated_per_window": float(n_new.mean()),
                    "text_tokens_per_window": float(n_text.mean()), "parallelism": f"dp{world} (independent windows)"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "cross_decode_kernel", "bytes_per_launch": bytes_per_launch,
-                     "windows_per_launch": windows_per_launch, "avg_launch_ms": avg_ms, "launches_timed": prof["timed"],
-                     "launches": prof["launches"],
+        "roofline": dict(dominant, **{
                      "region": f"{solo_steps} timed steps of this run with one batch in flight ({solo_ms:.1f} ms per step); with "
                                "several batches in flight a kernel's duration includes the time it shares the GPU with the others",
                      "overlapped": overlapped, "secondary": secondary,
-                     "path_model_ms": model_ms, "path_frac": model_ms / ms_per_step, "path_frac_one_in_flight": model_ms / solo_ms},
+                     "path_model_ms": model_ms, "path_frac": model_ms / ms_per_step, "path_frac_one_in_flight": model_ms / solo_ms}),
         "one_in_flight": {"value": 30.0 * n_global * solo_steps / solo_elapsed, "ms_per_step": solo_ms, "steps": solo_steps},
     }
     if rank == 0:

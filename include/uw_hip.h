@@ -153,9 +153,10 @@ int uw_transcribe_windows(uw_ctx* ctx, const float* audio, int64_t stride, const
 int uw_profile_begin(uw_ctx* ctx, int max_launches);
 int uw_profile_end(uw_ctx* ctx, int64_t* launches_total, int64_t* launches_timed, int64_t* windows_total,
                    double* timed_ms);
-/* Between the same begin / end, three more spans are bracketed with events, sparsely: kind 1 = launches of the
+/* Between the same begin / end, four more spans are bracketed with events, sparsely: kind 1 = launches of the
  * self-attention decode kernel (one in eight timed), 2 = the encoder pass of uw_transcribe_windows, 3 = the DTW launch
- * of uw_align.  Read after uw_profile_end: how many ran, how many were timed, the summed duration of the timed ones. */
+ * of uw_align, 4 = whole decode steps of the greedy loop (all launches of one step; one step in eight timed).  Read after
+ * uw_profile_end: how many ran, how many were timed, the summed duration of the timed ones. */
 int uw_profile_span(uw_ctx* ctx, int kind, int64_t* launches_total, int64_t* launches_timed, double* timed_ms);
 
 #ifdef __cplusplus

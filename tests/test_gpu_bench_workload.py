@@ -6,9 +6,12 @@ diarization-style prompt, N(0, 0.02^2) weights.
     positions) and from 16 KV-cached steps at self-attention lengths 171..186 after a 170-token prefill (the step
     kernels at 128 rows).  Tolerance: 1e-2 abs, the contract's bf16 figure, against the oracle evaluated in fp32 on
     the weights the bf16 engine holds (tests.helpers.bf16_weights).  Against the oracle on the ORIGINAL fp32 weights
-    the distance is reported and bounded by (oracle's own shift when its weights are rounded to bf16) + 1e-2: at this
-    depth rounding the weights alone moves the fp32 oracle's logits by about 1.5e-2, so no bf16-weight implementation
-    can be within 1e-2 of the fp32-weight logits.
+    the distance is bounded by fixed figures (what was measured, plus 10 %): at this depth rounding the weights alone
+    moves the fp32 oracle's logits by about 1.5e-2, so no bf16-weight implementation can be within 1e-2 of the
+    fp32-weight logits.
+  * bf16 free-running (the run the bench times) against fp32 free-running: greedy tokens of windows 0, 63 and 127 over
+    128 generated tokens -- the agreement rate and the first diverging step are reported; with random weights the two
+    best logits are often closer than the bf16 error, and one flip changes everything after it.
   * fp32: greedy tokens from the 170-token prompt identical to the reference's cache-less schedule on two different
     windows, attention rows within 1e-5, boundaries identical to the oracle's DTW on the GPU's cost matrix.
 """
@@ -26,6 +29,7 @@ from whisper_amd.weights import synthetic_state_dict
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 BF16_LOGITS_TOL = 1e-2
+FULL32_BOUND, STEP32_BOUND = 1.76e-2, 1.57e-2     # bf16 engine vs the oracle on fp32 weights: measured 1.60e-2 / 1.42e-2, + 10 %
 
 
 @pytest.fixture(scope="module")
@@ -82,7 +86,11 @@ def test_bench_workload_bf16_logits_within_contract(small):
               f"moves the oracle by {floor:.2e}); argmax agreement with the fp32 oracle {np.mean(agree):.2f}")
         assert worst_full <= BF16_LOGITS_TOL, worst_full
         assert worst_step <= BF16_LOGITS_TOL, worst_step
-        assert worst_full32 <= floor + BF16_LOGITS_TOL and worst_step32 <= floor + BF16_LOGITS_TOL
+        # distance to the fp32-WEIGHT oracle, the literal reading of the contract: above 1e-2 (rounding the weights alone
+        # moves the oracle by 1.49e-2 here), pinned at what was measured on MI355X (1.60e-2 / 1.42e-2) plus 10 % so that it
+        # cannot drift upwards unnoticed
+        assert abs(floor - 1.49e-2) < 1e-3, floor
+        assert worst_full32 <= FULL32_BOUND and worst_step32 <= STEP32_BOUND, (worst_full32, worst_step32)
     finally:
         eng.close()
 
@@ -116,3 +124,38 @@ def test_bench_prompt_fp32_tokens_rows_boundaries(small):
                 assert np.array_equal(bnd[b, : nt + 1], O.token_boundaries(i1, i2, nt))
     finally:
         eng.close()
+
+
+def test_bench_workload_free_running_token_agreement(small):
+    """The bench's own run (bf16, 128 windows, 170-token prompt, 128 generated tokens, free-running) beside the same
+    windows decoded in fp32 (whose tokens equal the oracle's, see the test above): how far do the token streams agree?"""
+    dims, sd, heads, om = small
+    B, n_gen = 128, 128
+    prompt = make_prompt(0)
+    P = len(prompt)
+    check = (0, 63, 127)
+    audio = np.stack([synth_audio(1234 + b) for b in range(B)])
+    n = torch.full((B,), 480000, dtype=torch.int32)
+    eng = E.Engine(dims, sd, dtype="bf16", max_batch=B, align_heads=heads)
+    try:
+        res = eng.transcribe_windows(torch.from_numpy(audio).to(DEV), n, [prompt] * B, P + n_gen, EOT, SOT, TS_BEGIN, TS_END)
+        got = {b: res["new_tokens"][b, : int(res["n_new"][b])].cpu().tolist() for b in check}
+    finally:
+        eng.close()
+    eng = E.Engine(dims, sd, dtype="f32", max_batch=len(check), align_heads=heads)
+    try:
+        res = eng.transcribe_windows(torch.from_numpy(audio[list(check)]).to(DEV), n[: len(check)], [prompt] * len(check), P + n_gen,
+                                     EOT, SOT, TS_BEGIN, TS_END)
+        ref = {b: res["new_tokens"][i, : int(res["n_new"][i])].cpu().tolist() for i, b in enumerate(check)}
+    finally:
+        eng.close()
+    first, rate = {}, {}
+    for b in check:
+        m = min(len(got[b]), len(ref[b]))
+        same = [got[b][i] == ref[b][i] for i in range(m)]
+        first[b] = same.index(False) if False in same else m
+        rate[b] = float(np.mean(same)) if m else 1.0
+    print(f"small B=128 P=170 free-running greedy, bf16 vs fp32: tokens equal up to step {first} of {n_gen}; agreement rate {rate}")
+    # every window starts out on the fp32 stream; how long it stays there depends on the margins of random weights
+    assert all(len(got[b]) == n_gen for b in check)
+    assert min(first.values()) >= 1, first

@@ -88,6 +88,9 @@ def test_one_real_size_window_matches_oracle_fp32(small):
         eng.close()
 
 
+# bf16 engine vs the oracle on fp32 WEIGHTS (the literal contract asks for 1e-2): measured 7.69e-3 / 1.04e-2 / 1.73e-2 /
+# 1.89e-2 / about 1.3e-2, of which rounding the weights to bf16 alone accounts for 7.6e-3 / 9.7e-3 / 1.76e-2 / 1.82e-2
+ERR32_BOUND = {"tiny.en": 8.5e-3, "base": 1.15e-2, "medium": 1.9e-2, "large-v3-turbo": 2.1e-2, "small": 1.6e-2}
 EN_ONLY = dict(sot=50257, eot=50256, ts_begin=50363, ts_end=50363 + 1500)      # the .en vocabularies sit one id lower
 
 
@@ -142,6 +145,7 @@ def test_baseline_configs_at_their_size(model, B):
         print(f"{model} B={B} bf16 max|dlogit|: {err:.2e} vs the fp32 oracle on the engine's bf16 weights, {err32:.2e} vs fp32 weights "
               f"(weight rounding alone: {floor:.2e})")
         assert err <= 1e-2, (model, err)      # bf16 contract figure
-        assert err32 <= floor + 1e-2, (model, err32, floor)
+        # against the fp32-weight oracle: a fixed bound per configuration, what was measured on MI355X plus 10 %
+        assert err32 <= ERR32_BOUND[model], (model, err32, floor)
     finally:
         eng.close()

@@ -93,9 +93,9 @@ struct uw_ctx {
     long prof_launches = 0;
     long prof_windows = 0;             // windows summed over the launches
     // secondary spans, sampled so that their events do not crowd the stream: 1 self-attention decode launches (one in
-    // eight), 2 the encoder pass, 3 the DTW launch
+    // eight), 2 the encoder pass, 3 the DTW launch, 4 whole decode steps of the greedy loop (one in eight)
     struct Span { std::vector<hipEvent_t> ev; size_t used = 0; long launches = 0; };
-    Span span[4];
+    Span span[5];
     // side streams: disjoint window ranges decode concurrently so one range's latency-bound small kernels
     // overlap another range's bandwidth-bound cross-attention stream
     hipStream_t sub_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -921,8 +921,8 @@ int uw_profile_begin(uw_ctx* c, int max_launches)
         UW_HIP_CHECK(hipEventCreate(&e));
         c->prof_ev.push_back(e);
     }
-    for (int k = 1; k < 4; ++k) {
-        const size_t want = k == 1 ? (size_t)max_launches / 4 + 2 : 128;
+    for (int k = 1; k < 5; ++k) {
+        const size_t want = k == 1 ? (size_t)max_launches / 4 + 2 : (k == 4 ? 512 : 128);
         while (c->span[k].ev.size() < want) {
             hipEvent_t e;
             UW_HIP_CHECK(hipEventCreate(&e));
@@ -958,7 +958,7 @@ int uw_profile_end(uw_ctx* c, int64_t* launches_total, int64_t* launches_timed, 
 
 int uw_profile_span(uw_ctx* c, int kind, int64_t* launches_total, int64_t* launches_timed, double* timed_ms)
 {
-    UW_REQUIRE(c && !c->prof_on && kind >= 1 && kind <= 3, "uw_profile_span: call after uw_profile_end with kind 1..3");
+    UW_REQUIRE(c && !c->prof_on && kind >= 1 && kind <= 4, "uw_profile_span: call after uw_profile_end with kind 1..4");
     uw_ctx::Span& sp = c->span[kind];
     double ms = 0.0;
     for (size_t i = 0; i + 1 < sp.used; i += 2) {
@@ -1102,9 +1102,11 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
                 sk.pos += b0; sk.n_new += b0; sk.n_text += b0; sk.active += b0; sk.dirty_from += b0; sk.max_new += b0; sk.failed += b0;
                 sk.n_active = c->st_n_active + k;
                 c->step_rows = std::min(c->Tm, Pmax + step);   // the longest prompt's position + 1 at this step
+                const int step_slot = span_begin(c, 4, 8, ss[k]);
                 RUN(decoder_step(c, b0, Bn, step == 0, ss[k]));
                 RUN(uw_greedy_next(c->dt, sk, c->logits + (long)b0 * c->logits_ld, c->logits_ld, Bn, c->V, eot, sot, ts_begin, ts_end,
                                    c->d_x + (long)b0 * c->d, c->tok_emb32, c->dec_pos, c->d, ss[k]));
+                span_end(c, 4, step_slot, ss[k]);
                 if ((step & 7) == 7 && step + 1 < max_steps) {
                     // non-blocking look at the counter copied 8 steps ago, then queue the next copy
                     if (step >= 15 && hipEventQuery(c->sub_event[k]) == hipSuccess && h_active[k] <= 0) sub_done[k] = true;

@@ -73,34 +73,11 @@ __device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsi
                  : "memory");
 }
 
-// Six of them in one statement (M0 saved once): the pieces of one ring stage of a four-wave tile kernel -- four of operand
-// A and two of operand B, each from its own wave-uniform base with per-lane offsets, into consecutive 4 KiB slabs.
-__device__ __forceinline__ void glds16_sv_4a2b(const void* abase, const unsigned (&aoff)[4], unsigned a_lds, const void* bbase,
-                                               const unsigned (&boff)[2], unsigned b_lds)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %9\n\t"
-                 "s_add_u32 m0, %7, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %9\n\t"
-                 "s_add_u32 m0, %7, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %9\n\t"
-                 "s_add_u32 m0, %7, 0x3000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %9\n\t"
-                 "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %10\n\t"
-                 "s_add_u32 m0, %8, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %10\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(aoff[0]), "v"(aoff[1]), "v"(aoff[2]), "v"(aoff[3]), "v"(boff[0]), "v"(boff[1]), "s"(a_lds), "s"(b_lds), "s"(abase),
-                   "s"(bbase)
-                 : "memory", "scc");
-}
-
 // s_waitcnt vmcnt(0) that the COMPILER sees (expcnt and lgkmcnt left alone).  Ordinary loads issued before a loop
 // whose first use is inside the loop make hipcc place a vmcnt wait at that use in every iteration -- and since it
 // does not count the asm-issued LDS DMAs, that wait is vmcnt(0) and drains the ring each time round.  Retiring
 // such loads with this builtin in front of the loop removes the in-loop waits.
 __device__ __forceinline__ void retire_vector_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
-// s_waitcnt lgkmcnt(0), likewise visible to the compiler: fragments read from LDS one loop iteration ahead are then known
-// to be in their registers, so no wait is inserted in front of the instructions that use them.
-__device__ __forceinline__ void retire_lds_reads() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 
 // Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an L2).  This bijection hands each
 // XCD a CONTIGUOUS run of tile indices, so tiles that share an operand panel hit the same L2 (speed only).

@@ -392,7 +392,10 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
 #pragma unroll
     for (int e = 0; e < R::E; ++e) q[e] = to_f32<T>(qkv[e]);
     const int n = pos + 1;
-    constexpr int U = NU > 0 ? NU : (sizeof(T) == 2 ? 8 : 4);   // loads in flight per lane (the cross kernel keeps 8 as well)
+    // loads in flight per lane; measured at 128 windows x 12 heads (1536 workgroups of about 60 KB each): 8 per lane, as
+    // the cross kernel keeps, is slower (23.1 against 21.6 us per launch), and so is requesting the first V round
+    // before the softmax (22.3 us) -- the workgroups are short enough that occupancy counts for more
+    constexpr int U = NU > 0 ? NU : 4;
     const int rows_per_round = 4 * R::RPI * U;
     // NU > 0: one round covers max_rows rows; a window beyond the launcher's bound (never in the greedy loop, whose
     // bound is exact) simply takes further rounds
@@ -412,13 +415,14 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
             if (sub == 0 && r < n) sc[r] = s;
         }
     }
-    // the first round of V rows is requested now, so the memory system stays busy while the workgroup does its softmax
-    // (with NU > 0 and a window inside the launcher's bound it is the only round)
+    const bool one_round = NU > 0 && n <= rows_per_round;   // block-uniform
+    if (one_round) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int r = (u * 4 + wave) * R::RPI + rin;
-        vv[u] = vnew;
-        if (r < pos) vv[u] = ld_stream(Vc + (long)r * ld);
+        for (int u = 0; u < U; ++u) {
+            const int r = (u * 4 + wave) * R::RPI + rin;
+            vv[u] = vnew;
+            if (r < pos) vv[u] = ld_stream(Vc + (long)r * ld);
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
 #pragma unroll
     for (int e = 0; e < R::E; ++e) acc[e] = 0.f;
     for (int r0 = 0; r0 < n; r0 += rows_per_round) {
-        if (r0 > 0) {
+        if (!one_round) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int r = r0 + (u * 4 + wave) * R::RPI + rin;

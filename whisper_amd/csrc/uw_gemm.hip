@@ -15,6 +15,7 @@
 #include "uw_kernels.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -328,11 +329,12 @@ constexpr int K3_ROW = 64;                                         // bytes of K
 constexpr int A3_BYTES = B2M * K3_ROW, B3_BYTES = B2N * K3_ROW, STAGE3 = A3_BYTES + B3_BYTES;   // 24 KiB
 constexpr int NSTAGE3 = 3;
 
-// ---- pieces shared by the two-workgroup tile kernels (gemm_tn_duo_kernel: 8 waves of 64 x 64, gemm_tn_quad_kernel: 4 waves
-// of 128 x 64) ----
+// ---- pieces of the two-workgroup tile kernel (prologue, epilogue, tile order), templated on the wave's row tiles so that the
+// development variants in tools/gemm_variants.hip share them ----
 
 // tile of this workgroup: batch item and origin.  false: the block lies in the padding of a panel-ordered grid.
-__device__ __forceinline__ bool tile_origin(const GemmParams& p, int tiles_n, int tiles_mn, int total, long& bz, int& m0, int& n0)
+__device__ __forceinline__ bool tile_origin_v(const GemmParams& p, int vt, int bn, int tiles_n, int tiles_mn, int total, long& bz,
+                                              int& m0, int& n0)
 {
     if (p.panel_n > 0) {
         // Column-panel order (batch 1): the row bands are cut into eight runs, one per XCD (blocks b and b + 8 share
@@ -340,23 +342,27 @@ __device__ __forceinline__ bool tile_origin(const GemmParams& p, int tiles_n, in
         // moves to the next panel.  The panel's weight rows then stay in that XCD's L2 while the activation bands
         // stream past; in plain row-major order a weight matrix larger than the L2 is fetched again for every row band.
         const int tiles_m = tiles_mn / tiles_n, bands = (tiles_m + 7) >> 3;
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int xcd = vt & 7, idx = vt >> 3;
         const int band0 = xcd * bands, nb = min(bands, tiles_m - band0);
-        if (nb <= 0 || idx >= nb * tiles_n) return false;      // the grid is padded to 8 * bands * tiles_n blocks
+        if (nb <= 0 || idx >= nb * tiles_n) return false;      // the index space is padded to 8 * bands * tiles_n
         const int per_panel = nb * p.panel_n;
         const int pn = idx / per_panel, rem = idx - pn * per_panel;
         const int pw = min(p.panel_n, tiles_n - pn * p.panel_n);    // the last panel may be narrower
         bz = 0;
         m0 = (band0 + rem / pw) * B2M;
-        n0 = (pn * p.panel_n + rem % pw) * B2N;
+        n0 = (pn * p.panel_n + rem % pw) * bn;
     } else {
-        const int vt = xcd_contiguous_tile(blockIdx.x, total);
-        bz = vt / tiles_mn;
-        const int tile = vt % tiles_mn;
+        const int ct = xcd_contiguous_tile(vt, total);
+        bz = ct / tiles_mn;
+        const int tile = ct % tiles_mn;
         m0 = (tile / tiles_n) * B2M;
-        n0 = (tile % tiles_n) * B2N;
+        n0 = (tile % tiles_n) * bn;
     }
     return true;
+}
+__device__ __forceinline__ bool tile_origin(const GemmParams& p, int tiles_n, int tiles_mn, int total, long& bz, int& m0, int& n0)
+{
+    return tile_origin_v(p, (int)blockIdx.x, B2N, tiles_n, tiles_mn, total, bz, m0, n0);
 }
 
 // The accumulators start at bias + residual: those loads ride behind the first K-stages instead of opening the
@@ -591,152 +597,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     tile_epilogue<T, TC, 4>(p, acc, (float*)smem + wave * (32 * EP_PITCH), m0 + wr * 64, n0 + wc * 64, bz, lane, R, r_late);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Same 256 x 128 tile, stage layout and epilogue as gemm_tn_duo_kernel, with FOUR waves of 128 x 64 instead of eight of
-// 64 x 64 and the operand fragments of the NEXT K-step fetched from LDS into a second register set while the matrix
-// cores work on the current one.  A 64 x 64 wave tile reads 8 KiB of LDS per 16 MFMAs, which with sixteen waves on a CU
-// keeps the LDS busy for as many cycles as the matrix cores; the 128 x 64 tile reads 12 KiB per 32 MFMAs (a quarter
-// less per flop), and because its reads run one K-step ahead no MFMA waits on an LDS round trip.  Two workgroups per CU
-// (2 waves per SIMD, up to 256 registers each), so one workgroup's epilogue still overlaps the other's loop.
-// Ring protocol (3 stages): at the top of step k the wave waits for its own DMA pieces of stage k+1 and for its fragment
-// reads of stage k, then the barrier makes stage k+1 visible and guarantees that every wave is done reading stage k from
-// LDS -- so stage k+3 may be requested into that slot -- then fragments k+1 are read while step k multiplies.
-constexpr int Q_WAVES = 4, Q_TM = 8;
-
-template <typename T, typename TC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_tn_quad_kernel(GemmParams p)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int E = 16 / (int)sizeof(T);
-    constexpr int KT = K3_ROW / (int)sizeof(T);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int tiles_n = (p.N + B2N - 1) / B2N;
-    const int tiles_mn = tiles_n * ((p.M + B2M - 1) / B2M), total = tiles_mn * p.batch;
-    const int frow = lane & 15, fg = lane >> 4;
-    const unsigned lds_base = lds_addr_of(smem) + wave * 1024;
-    long bz;
-    int m0, n0;
-    if (!tile_origin(p, tiles_n, tiles_mn, total, bz, m0, n0)) return;
-    const T* __restrict__ A = (const T*)p.A + bz * p.sA;
-    const T* __restrict__ B = (const T*)p.B + bz * p.sB;
-
-    unsigned offA[4], offB[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int L = i * 256 + tid, row = L >> 2, c = (L & 3) ^ ((-(row >> 2)) & 3);
-        offA[i] = (unsigned)(((long)(min(m0 + row, p.M - 1) - m0) * p.lda + c * E) * (long)sizeof(T));
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int L = i * 256 + tid, row = L >> 2, c = (L & 3) ^ ((-(row >> 2)) & 3);
-        offB[i] = (unsigned)(((long)(min(n0 + row, p.N - 1) - n0) * p.ldb + c * E) * (long)sizeof(T));
-    }
-    const T* baseA = A + (long)m0 * p.lda;
-    const T* baseB = B + (long)n0 * p.ldb;
-    const int wrap_a = p.kwrap_a ? p.kwrap_a / KT : 0x7fffffff, wrap_b = p.kwrap_b ? p.kwrap_b / KT : 0x7fffffff;
-    const long step_a = p.kstep_a ? p.kstep_a : KT, step_b = p.kstep_b ? p.kstep_b : KT;
-    const int nk = p.K / KT;
-    // the stage to request next: its K index, ring slot and operand addresses advance together (a split operand's
-    // partner starts over after the wrap length), so a request costs a handful of scalar instructions
-    int kt_next = 0, slot_next = 0;
-    const T* ka = baseA;
-    const T* kb = baseB;
-    auto stage_next = [&]() {
-        const unsigned a_dst = lds_base + slot_next * STAGE3;
-#ifdef UW_TUNE   // timing-only builds (tools/gemm_bench.hip): leave out part of the operand traffic to see what bounds the loop
-        if (p.act & 8) { glds16_sv(kb, offB[0], a_dst + A3_BYTES); glds16_sv(kb, offB[1], a_dst + A3_BYTES + 4096);
-                         glds16_sv(kb, offB[0], a_dst + A3_BYTES); glds16_sv(kb, offB[1], a_dst + A3_BYTES + 4096);
-                         glds16_sv(kb, offB[0], a_dst + A3_BYTES); glds16_sv(kb, offB[1], a_dst + A3_BYTES + 4096); }
-        else if (p.act & 16) { glds16_sv(ka, offA[0], a_dst); glds16_sv(ka, offA[0], a_dst); glds16_sv(ka, offA[0], a_dst);
-                               glds16_sv(ka, offA[0], a_dst); glds16_sv(ka, offA[0], a_dst); glds16_sv(ka, offA[0], a_dst); }
-        else
-#endif
-        glds16_sv_4a2b(ka, offA, a_dst, kb, offB, a_dst + A3_BYTES);
-        ++kt_next;
-        slot_next = slot_next == NSTAGE3 - 1 ? 0 : slot_next + 1;
-        ka = kt_next == wrap_a ? baseA : ka + step_a;
-        kb = kt_next == wrap_b ? baseB : kb + step_b;
-    };
-    stage_next();
-    if (nk > 1) stage_next();
-    if (nk > 2) stage_next();
-    const float* __restrict__ R = p.residual ? p.residual + bz * p.sR : nullptr;
-    const bool r_vec = (p.ldr & 3) == 0;
-    const bool r_late = sizeof(TC) == 4 && R && r_vec && p.ldr == p.ldc && !p.c_group && !p.c_kblock && (p.ldc & 3) == 0;
-    f32x4 acc[Q_TM][4];
-    tile_acc_init<Q_TM>(p, acc, m0 + wr * 128, n0 + wc * 64, frow, fg, R, r_late, r_vec);
-    retire_vector_loads();   // bias / residual are in the accumulators, and the first three stages have landed
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    // lane's fragment address inside a stage: rows t*16 + frow of the wave's block, chunk position by the row's swizzle
-    const int pos = (fg ^ ((-(frow >> 2)) & 3)) << 4;
-    const char* a_lane = smem + (wr * 128 + frow) * K3_ROW + pos;
-    const char* b_lane = smem + A3_BYTES + (wc * 64 + frow) * K3_ROW + pos;
-    uint4 af[2][Q_TM], bf[2][4];
-    auto read_frags = [&](int st, uint4 (&a)[Q_TM], uint4 (&b)[4]) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = *(const uint4*)(b_lane + st * STAGE3 + t * 16 * K3_ROW);
-#pragma unroll
-        for (int t = 0; t < Q_TM; ++t) a[t] = *(const uint4*)(a_lane + st * STAGE3 + t * 16 * K3_ROW);
-    };
-    auto mma_step = [&](const uint4 (&a)[Q_TM], const uint4 (&b)[4]) {
-#pragma unroll
-        for (int tm = 0; tm < Q_TM; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) mma16<T>(b[tn], a[tm], acc[tm][tn]);
-    };
-    int slot_read = 1;           // ring slot of stage kt + 1, the one whose fragments are read next
-    // one K-step that is not the last: `ca / cb` hold the fragments of step kt (read during the previous step),
-    // `na / nb` receive those of kt + 1 while step kt multiplies
-    auto k_step = [&](int kt, const uint4 (&ca)[Q_TM], const uint4 (&cb)[4], uint4 (&na)[Q_TM], uint4 (&nb)[4]) {
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // all but the six pieces of stage kt + 2
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        retire_lds_reads();                                                 // this wave's reads of stage kt are in registers
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        read_frags(slot_read, na, nb);
-        slot_read = slot_read == NSTAGE3 - 1 ? 0 : slot_read + 1;
-        if (kt_next < nk) stage_next();                                     // into the slot of stage kt: nobody reads it any more
-        mma_step(ca, cb);
-    };
-    // nk - 1 steps fetch ahead, the last one only multiplies.  The fragments alternate between the two register sets; an
-    // odd number of fetching steps starts in set 1, so that the last step always finds its fragments in set 0.
-    int kt = 0;
-    if ((nk - 1) & 1) {
-        read_frags(0, af[1], bf[1]);
-        k_step(0, af[1], bf[1], af[0], bf[0]);
-        kt = 1;
-    } else {
-        read_frags(0, af[0], bf[0]);
-    }
-    for (; kt + 1 < nk; kt += 2) {
-        k_step(kt, af[0], bf[0], af[1], bf[1]);
-        k_step(kt + 1, af[1], bf[1], af[0], bf[0]);
-    }
-    retire_lds_reads();
-    mma_step(af[0], bf[0]);
-    // ---- epilogue: four quarters of 32 rows per wave through the idle ring ----
-    __syncthreads();
-    tile_epilogue<T, TC, Q_TM>(p, acc, (float*)smem + wave * (32 * EP_PITCH), m0 + wr * 128, n0 + wc * 64, bz, lane, R, r_late);
-}
-
 // Column tiles per panel for the panel order of gemm_tn_duo_kernel, or 0 for the plain order.  Model of the bytes an
 // XCD pulls through the fabric beyond the algorithmic ones: in plain order a weight matrix that does not fit the 4 MiB
 // L2 beside the activation bands is fetched again for every row band when K is short (tiles of one band do not stay in
 // step); with n panels the activation matrix is read n times instead of once.  Panels are used when that is less.
-static int choose_panel(long es, const GemmParams& p)
+static int choose_panel(long es, const GemmParams& p, int bn = B2N)
 {
     static const int forced = getenv("UW_GEMM_PANEL") ? atoi(getenv("UW_GEMM_PANEL")) : -1;   // development knob
-    const int tiles_m = ceil_div(p.M, B2M), tiles_n = ceil_div(p.N, B2N);
+    const int tiles_m = ceil_div(p.M, B2M), tiles_n = ceil_div(p.N, bn);
     if (p.batch != 1 || tiles_m < 64 || tiles_n < 2) return 0;
     if (forced >= 0) return forced >= tiles_n ? 0 : forced;
     const long w_bytes = (long)p.N * p.K * es, a_bytes = (long)p.M * p.K * es;
     if (w_bytes <= 3l << 20) return 0;                          // the whole weight matrix stays in L2 anyway
     const long panel_cap = 5l << 19;                            // 2.5 MiB of weights per panel
-    int pw = (int)std::max<long>(1, panel_cap / ((long)B2N * p.K * es));
+    int pw = (int)std::max<long>(1, panel_cap / ((long)bn * p.K * es));
     const int n_panels = ceil_div(tiles_n, pw);
     pw = ceil_div(tiles_n, n_panels);                           // even panels
     if (n_panels < 2) return 0;
@@ -773,18 +647,7 @@ template <typename T, typename TC> int launch_duo(const GemmParams& p, hipStream
     GemmParams q = p;
     q.panel_n = choose_panel((long)sizeof(T), p);
     if (q.panel_n > 0) grid = 8u * (unsigned)ceil_div(ceil_div(p.M, B2M), 8) * (unsigned)ceil_div(p.N, B2N);
-    // 4 waves of 128 x 64 with register-prefetched fragments (default), or 8 waves of 64 x 64 (UW_GEMM_WAVES=8)
-    static const int waves = getenv("UW_GEMM_WAVES") ? atoi(getenv("UW_GEMM_WAVES")) : 4;
-    if (waves == 8) {
-        hipLaunchKernelGGL((gemm_tn_duo_kernel<T, TC>), dim3(grid), dim3(512), lds, s, q);
-    } else {
-        static PerDeviceFlag attr_set_q;
-        if (attr_set_q.pending()) {
-            UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_tn_quad_kernel<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set_q.mark();
-        }
-        hipLaunchKernelGGL((gemm_tn_quad_kernel<T, TC>), dim3(grid), dim3(256), lds, s, q);
-    }
+    hipLaunchKernelGGL((gemm_tn_duo_kernel<T, TC>), dim3(grid), dim3(512), lds, s, q);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }

@@ -86,7 +86,7 @@ class Engine:
         total, timed, windows, ms = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
         L.check(self.lib.uw_profile_end(self.ctx, C.byref(total), C.byref(timed), C.byref(windows), C.byref(ms)))
         out = {"launches": total.value, "timed": timed.value, "windows": windows.value, "timed_ms": ms.value}
-        for kind, name in ((1, "self_decode"), (2, "encoder"), (3, "dtw")):
+        for kind, name in ((1, "self_decode"), (2, "encoder"), (3, "dtw"), (4, "decode_step")):
             L.check(self.lib.uw_profile_span(self.ctx, kind, C.byref(total), C.byref(timed), C.byref(ms)))
             out[name] = {"launches": total.value, "timed": timed.value, "timed_ms": ms.value}
         return out

@@ -100,10 +100,25 @@ def _stop_workers(jobs: "queue.Queue", n: int) -> None:
         jobs.put(None)
 
 
-def _worker_loop(jobs: "queue.Queue", eng) -> None:
+_streams: Dict[tuple, "torch.cuda.Stream"] = {}       # (device index, worker slot) -> stream, reused by later pools
+_streams_lock = threading.Lock()
+
+
+def _worker_stream(device: torch.device, slot: int) -> "torch.cuda.Stream":
+    """The HIP stream of worker `slot` on `device`.  Streams are kept and handed to the next pool's worker of the same
+    slot: a stream brings a hardware queue and its scratch memory with it, so pools that come and go (one per
+    whisperer(inflight=...) call) must not create new ones each time."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
+    with _streams_lock:
+        if key not in _streams:
+            _streams[key] = torch.cuda.Stream(device=device)   # non-blocking: does not serialise with the other workers
+        return _streams[key]
+
+
+def _worker_loop(jobs: "queue.Queue", eng, slot: int = 0) -> None:
     """One worker: its own engine (library context), its own HIP stream, jobs from the shared queue."""
     torch.cuda.set_device(eng.device)
-    stream = torch.cuda.Stream(device=eng.device)        # non-blocking: does not serialise with the other workers
+    stream = _worker_stream(eng.device, slot)
     while True:
         job = jobs.get()
         if job is None:
@@ -157,7 +172,7 @@ class EnginePool:
         self._jobs: "queue.Queue" = queue.Queue()
         # the workers know the job queue and their own engine, not the pool: a pool nobody refers to any more is
         # collected, and its finalizer posts the stop sentinels so that threads, contexts and their memory go with it
-        self._threads = [threading.Thread(target=_worker_loop, args=(self._jobs, e), daemon=True) for e in self.engines]
+        self._threads = [threading.Thread(target=_worker_loop, args=(self._jobs, e, k), daemon=True) for k, e in enumerate(self.engines)]
         for t in self._threads:
             t.start()
         self._finalizer = weakref.finalize(self, _stop_workers, self._jobs, len(self._threads))
