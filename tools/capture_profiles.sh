@@ -6,12 +6,15 @@
 #   2. PMC passes, one counter block per run (never mixed with a trace): FETCH_SIZE, WRITE_SIZE, SQ busy / wait counters
 #      (a TCC_HIT / TCC_MISS pass over this program produced no output for three minutes on this pool and is left out)
 #                                                               -> gpurun_out/<tag>_pmc_summary.txt
-# Usage: tools/capture_profiles.sh <tag>        (copy the summaries you want kept into profiles/)
+# Usage: tools/capture_profiles.sh <tag> [all|main|configs|pmc]   (copy the summaries you want kept into profiles/)
 set -o pipefail
 TAG=${1:-r03}
+PART=${2:-all}
+want() { [ "$PART" = all ] || [ "$PART" = "$1" ]; }
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out
 BENCH="python3 bench.py --inflight 1 --steps 1 --solo-steps 1 --warmup 1 --no-cpu-baseline"
+if want main; then
 # one batch in flight: kernel durations as the roofline figures use them (1 warm-up + 1 + 1 timed passes)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- python3 bench.py --inflight 1 --steps 1 --solo-steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace.log 2>&1 || exit 1
 python3 tools/prof_summary.py $OUT/${TAG}_trace 3 > $OUT/${TAG}_bench_small_b128_kernel_trace_summary.txt || exit 1
@@ -20,6 +23,8 @@ rm -rf $OUT/${TAG}_trace
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace3 -o t -- python3 bench.py --steps 6 --solo-steps 1 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_trace3.log 2>&1 || exit 1
 python3 tools/prof_summary.py $OUT/${TAG}_trace3 10 > $OUT/${TAG}_bench_small_b128_inflight3_kernel_trace_summary.txt || exit 1
 rm -rf $OUT/${TAG}_trace3
+fi
+if want configs; then
 # the other BASELINE configurations: bench line first (un-profiled timings), then a kernel trace of one batch in flight
 for cfg in "base 32" "medium 15" "large-v3-turbo 32" "tiny.en 1"; do
   set -- $cfg; model=$1; batch=$2; name=${model}_b${batch}
@@ -29,6 +34,8 @@ for cfg in "base 32" "medium 15" "large-v3-turbo 32" "tiny.en 1"; do
   rm -rf $OUT/${TAG}_trace_$name
   echo "config $name done"
 done
+fi
+want pmc || exit 0
 {
   echo "# rocprofv3 --pmc passes (one counter block per run) over: $BENCH   (3 passes of the path in each run, one batch in flight)"
   echo "# whisper-small shapes, 128 windows, bf16, 170-token prompt, 128 generated tokens.  FETCH_SIZE / WRITE_SIZE are in KiB;"

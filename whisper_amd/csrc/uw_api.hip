@@ -104,6 +104,7 @@ struct uw_ctx {
     int n_streams = 4;
     int split_mode = -1;           // cross-attention decode: -1 choose by grid size, 0 never split, n > 1 always n parts
     float* split_ws = nullptr;
+    int32_t* split_ticket = nullptr;   // [Bm][H] arrival counters of the row-split cross-attention (zero between launches)
 };
 
 namespace {
@@ -377,6 +378,7 @@ int alloc_workspace(uw_ctx* c)
     ALLOC(c->d_mlp, Bm * Tm * 8 * d * es, true);
     ALLOC(c->d_last, ((Bm + 15) & ~15l) * d * 4, true);
     ALLOC(c->split_ws, Bm * (d / 64) * 16 * 66 * 4, true);
+    ALLOC(c->split_ticket, Bm * (d / 64) * 4, true);
     c->logits_ld = (c->V + 3) & ~3;
     ALLOC(c->logits, Bm * c->logits_ld * 4, true);
     if (c->n_sel > 0) {
@@ -741,6 +743,7 @@ int decoder_step_chunk(uw_ctx* c, int b0, int B, bool embed, hipStream_t s)
         // a handful of (window, head) pairs (single-window use): cut the frames over several workgroups
         cp.n_split = c->split_mode >= 0 ? std::max(1, c->split_mode) : (H * B >= 64 ? 1 : 8);
         cp.split_ws = c->split_ws + (long)b0 * H * 16 * 66;
+        cp.split_ticket = c->split_ticket + (long)b0 * H;
         const bool timed = c->prof_on && c->prof_used + 2 <= c->prof_ev.size();
         if (timed) UW_HIP_CHECK(hipEventRecord(c->prof_ev[c->prof_used], s));
         RUN(uw_cross_attn_decode(c->dt, cp, s));

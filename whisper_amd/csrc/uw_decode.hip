@@ -66,6 +66,29 @@ template <typename T> __device__ __forceinline__ float row_sum(float v)
     return v;
 }
 
+// Data handed from one workgroup to another INSIDE a launch (the part records and raw scores of the row-split
+// cross-attention) goes through device-scope stores and loads, which pass the per-XCD L2 instead of being kept in
+// it; the producer waits for its stores before it takes the ticket.  A device-scope fence would do too, but it
+// writes back and invalidates the whole L2 of the XCD for every workgroup that executes it (measured on a full
+// batch: decode steps 5x slower).  Such a hand-over costs three dependent round trips through the fabric (store
+// acknowledged, ticket, load) -- about what the launch it replaces costs, so it only pays where it replaces a launch
+// outright and adds no work in front of it.
+__device__ __forceinline__ void st_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// true for the workgroup that arrives last of `n`; the counter is left at zero for the next launch.  All threads call.
+__device__ __forceinline__ bool last_arrival(int32_t* counter, int n, int tid, int* flag)
+{
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's stores have been acknowledged
+    __syncthreads();
+    if (tid == 0) {
+        const bool last = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n - 1;
+        if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // cross-attention for one new token: grid (H, B), NW waves per workgroup (4 when the grid fills the chip several
 // times over, more when it does not: the bytes in flight per CU are what covers the HBM latency)
@@ -193,11 +216,59 @@ __global__ __launch_bounds__(64 * NW) void cross_decode_kernel(CrossDecodeParams
     }
 }
 
+// End of a part's workgroup (256 threads): the one that takes the last ticket of its (window, head) merges the parts in
+// part order -- maxima, exp-sums, the 64 accumulators -- and turns an alignment head's raw scores into probabilities;
+// everything it needs is requested in one go.
+template <typename T>
+__device__ __forceinline__ void split_finish(const CrossDecodeParams& p, int b, int h, int tid)
+{
+    __shared__ float s_m[16], s_l[16];
+    __shared__ int s_flag;
+    if (!last_arrival(p.split_ticket + (long)b * p.H + h, p.n_split, tid, &s_flag)) return;
+    const float* ws = p.split_ws + ((long)b * p.H + h) * p.n_split * 66;
+    if (tid < p.n_split) { s_m[tid] = ld_dev(ws + tid * 66); s_l[tid] = ld_dev(ws + tid * 66 + 1); }
+    float part[16];
+#pragma unroll
+    for (int z = 0; z < 16; ++z) part[z] = (tid < 64 && z < p.n_split) ? ld_dev(ws + z * 66 + 2 + tid) : 0.f;
+    const int slot = p.sel_slot[h];
+    float* row = nullptr;
+    if (p.rows && slot >= 0) {
+        const int ri = p.row_index[b];
+        if (ri >= 0 && ri < p.n_rows_max) row = p.rows + (long)b * p.rows_sB + (long)slot * p.rows_sSel + (long)ri * p.S;
+    }
+    float rv[8];      // raw scores of an alignment head's row, 256 threads x 8 >= 1500 frames (longer rows loop below)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rv[k] = (row && tid + k * 256 < p.S) ? ld_dev(row + tid + k * 256) : 0.f;
+    __syncthreads();
+    float M = -INFINITY;
+    for (int z = 0; z < p.n_split; ++z) M = fmaxf(M, s_m[z]);
+    float L = 0.f, o = 0.f;
+#pragma unroll
+    for (int z = 0; z < 16; ++z) {
+        if (z < p.n_split) {
+            const float sc = __expf(s_m[z] - M);
+            L += s_l[z] * sc;
+            o += part[z] * sc;
+        }
+    }
+    const float inv = 1.0f / L;
+    if (row) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (tid + k * 256 < p.S) row[tid + k * 256] = __expf(rv[k] - M) * inv;
+        for (int j = tid + 2048; j < p.S; j += 256) row[j] = __expf(ld_dev(row + j) - M) * inv;
+    }
+    if (tid < 64) {
+        const long at = p.out_packed ? frag_elem_offset<T>(b, h * 64 + tid, p.d) : (long)b * p.d + h * 64 + tid;
+        store_split<T>(p.out, p.out_lo, at, o * inv);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Small batches: (H, B) workgroups cannot fill 256 CUs, so the 1500 rows of a (window, head) are cut over
 // n_split workgroups.  Each leaves (local max, local exp-sum, 64 unnormalised accumulators) and, for an alignment
-// head, its raw scores in the rows buffer; the combine pass merges the parts and turns the scores into
-// probabilities.  grid (H, B, n_split), 256 threads.
+// head, its raw scores in the rows buffer; the workgroup that finishes last merges the parts (split_finish): no
+// second launch, and the merge order does not depend on which one that is.  grid (H, B, n_split), 256 threads.
 template <typename T>
 __global__ __launch_bounds__(256) void cross_decode_split_kernel(CrossDecodeParams p)
 {
@@ -213,7 +284,8 @@ __global__ __launch_bounds__(256) void cross_decode_split_kernel(CrossDecodePara
     float* ws = p.split_ws + (((long)b * p.H + h) * p.n_split + z) * 66;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (S <= 0) {
-        if (tid < 66) ws[tid] = tid == 0 ? -INFINITY : 0.f;
+        if (tid < 66) st_dev(ws + tid, tid == 0 ? -INFINITY : 0.f);
+        split_finish<T>(p, b, h, tid);
         return;
     }
     const int sub = lane % R::LPR, rin = lane / R::LPR;
@@ -259,7 +331,7 @@ __global__ __launch_bounds__(256) void cross_decode_split_kernel(CrossDecodePara
     float mx = -INFINITY;
     for (int j = tid; j < S; j += 256) {
         mx = fmaxf(mx, sc[j]);
-        if (row_out) row_out[j] = sc[j];      // raw score; the combine pass makes it a probability
+        if (row_out) st_dev(row_out + j, sc[j]);      // raw score; the merge makes it a probability
     }
     mx = wave_max(mx);
     if (lane == 0) red[wave] = mx;
@@ -305,57 +377,10 @@ __global__ __launch_bounds__(256) void cross_decode_split_kernel(CrossDecodePara
         for (int e = 0; e < R::E; ++e) part[wave * 64 + sub * R::E + e] = acc[e];
     }
     __syncthreads();
-    if (tid < 64) ws[2 + tid] = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
-    if (tid == 64) ws[0] = mx;
-    if (tid == 65) ws[1] = (red[4] + red[5]) + (red[6] + red[7]);
-}
-
-// merges the parts of one (window, head) in part order; grid (H, B), 256 threads.  Everything the workgroup needs
-// (the parts' maxima and sums, its 64 x n_split accumulators) is requested in one go: the kernel is a handful of
-// dependent memory round trips and nothing else.
-template <typename T>
-__global__ __launch_bounds__(256) void cross_combine_kernel(CrossDecodeParams p)
-{
-    __shared__ float s_m[16], s_l[16];
-    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    if (p.active && !p.active[b]) return;
-    const float* ws = p.split_ws + ((long)b * p.H + h) * p.n_split * 66;
-    if (tid < p.n_split) { s_m[tid] = ws[tid * 66]; s_l[tid] = ws[tid * 66 + 1]; }
-    float part[16];
-#pragma unroll
-    for (int z = 0; z < 16; ++z) part[z] = (tid < 64 && z < p.n_split) ? ws[z * 66 + 2 + tid] : 0.f;
-    const int slot = p.sel_slot[h];
-    float* row = nullptr;
-    if (p.rows && slot >= 0) {
-        const int ri = p.row_index[b];
-        if (ri >= 0 && ri < p.n_rows_max) row = p.rows + (long)b * p.rows_sB + (long)slot * p.rows_sSel + (long)ri * p.S;
-    }
-    float rv[8];      // raw scores of an alignment head's row, 256 threads x 8 >= 1500 frames (longer rows loop below)
-#pragma unroll
-    for (int k = 0; k < 8; ++k) rv[k] = (row && tid + k * 256 < p.S) ? row[tid + k * 256] : 0.f;
-    __syncthreads();
-    float M = -INFINITY;
-    for (int z = 0; z < p.n_split; ++z) M = fmaxf(M, s_m[z]);
-    float L = 0.f, o = 0.f;
-#pragma unroll
-    for (int z = 0; z < 16; ++z) {
-        if (z < p.n_split) {
-            const float sc = __expf(s_m[z] - M);
-            L += s_l[z] * sc;
-            o += part[z] * sc;
-        }
-    }
-    const float inv = 1.0f / L;
-    if (tid < 64) {
-        const long at = p.out_packed ? frag_elem_offset<T>(b, h * 64 + tid, p.d) : (long)b * p.d + h * 64 + tid;
-        store_split<T>(p.out, p.out_lo, at, o * inv);
-    }
-    if (row) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (tid + k * 256 < p.S) row[tid + k * 256] = __expf(rv[k] - M) * inv;
-        for (int j = tid + 2048; j < p.S; j += 256) row[j] = __expf(row[j] - M) * inv;
-    }
+    if (tid < 64) st_dev(ws + 2 + tid, (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]));
+    if (tid == 64) st_dev(ws, mx);
+    if (tid == 65) st_dev(ws + 1, (red[4] + red[5]) + (red[6] + red[7]));
+    split_finish<T>(p, b, h, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,6 +519,12 @@ __global__ __launch_bounds__(1024) void greedy_next_kernel(GreedyState st, const
     __shared__ int s_next[2];
     const int b = blockIdx.x;
     if (!st.active[b]) return;
+    // the window's counters and the next position's embedding row do not depend on the arg-max: they are requested
+    // first, so their round trips pass under the scan of the logits row instead of following it one by one
+    const int pos0 = st.pos[b], nn0 = st.n_new[b], nt0 = st.n_text[b], dirty0 = st.dirty_from[b], budget0 = st.max_new[b];
+    const int n_ctx_rows = st.ld_tok;               // positions 0 .. ld_tok - 1 exist
+    f32x4 pe_next = {0.f, 0.f, 0.f, 0.f};
+    if ((int)threadIdx.x < (d >> 2)) pe_next = ((const f32x4*)(pos_emb + (long)min(pos0 + 1, n_ctx_rows - 1) * d))[threadIdx.x];
     bool nan_row = false;
     const int tok = block_argmax_1024(logits + (long)b * ld, V, sv, si, &nan_row);
     if (threadIdx.x == 0) {
@@ -507,20 +538,19 @@ __global__ __launch_bounds__(1024) void greedy_next_kernel(GreedyState st, const
         } else if (tok == eot) {
             alive = false;
         } else {
-            idx = st.pos[b] + 1;   // pos = index of the token that produced these logits
+            idx = pos0 + 1;   // pos = index of the token that produced these logits
             st.tokens[(long)b * st.ld_tok + idx] = tok;
             st.pos[b] = idx;
-            const int nn = st.n_new[b] + 1;
+            const int nn = nn0 + 1;
             st.n_new[b] = nn;
             const bool is_text = tok < sot && !(tok >= ts_begin && tok <= ts_end);
             if (is_text) {
-                const int nt = st.n_text[b];
-                st.text_ids[(long)b * st.ld_tok + nt] = tok;
-                st.n_text[b] = nt + 1;
-            } else if (st.dirty_from[b] < 0) {
-                st.dirty_from[b] = st.n_text[b];  // rows captured from here on see a context the reference never builds
+                st.text_ids[(long)b * st.ld_tok + nt0] = tok;
+                st.n_text[b] = nt0 + 1;
+            } else if (dirty0 < 0) {
+                st.dirty_from[b] = nt0;  // rows captured from here on see a context the reference never builds
             }
-            if (nn >= st.max_new[b]) alive = false;
+            if (nn >= budget0) alive = false;
         }
         if (!alive) {
             st.active[b] = 0;
@@ -532,9 +562,8 @@ __global__ __launch_bounds__(1024) void greedy_next_kernel(GreedyState st, const
     __syncthreads();
     const int pos = s_next[0];
     if (pos < 0) return;
-    const f32x4* e = (const f32x4*)(tok_emb + (long)min(max(s_next[1], 0), V - 1) * d);
-    const f32x4* pe = (const f32x4*)(pos_emb + (long)pos * d);
-    for (int i = threadIdx.x; i < (d >> 2); i += 1024) *(f32x4*)(x + x_elem_offset<T>(b, i * 4, d)) = e[i] + pe[i];
+    const f32x4* e = (const f32x4*)(tok_emb + (long)min(max(s_next[1], 0), V - 1) * d);   // pos == pos0 + 1 here
+    if ((int)threadIdx.x < (d >> 2)) *(f32x4*)(x + x_elem_offset<T>(b, threadIdx.x * 4, d)) = e[threadIdx.x] + pe_next;
 }
 
 }  // namespace
@@ -545,17 +574,12 @@ int uw_cross_attn_decode(int dtype, const CrossDecodeParams& p, hipStream_t s)
                "cross_attn_decode: bad arguments");
     UW_REQUIRE(!p.rows || p.row_index, "cross_attn_decode: rows without row_index");
     if (p.n_split > 1) {
-        UW_REQUIRE(p.split_ws && p.n_split <= 16, "cross_attn_decode: split needs a workspace and at most 16 parts");
+        UW_REQUIRE(p.split_ws && p.split_ticket && p.n_split <= 16, "cross_attn_decode: split needs a workspace, tickets and at most 16 parts");
         const int per = (((p.S + p.n_split - 1) / p.n_split) + 31) & ~31;
         const size_t lds = (size_t)(per + 8 + 256) * 4;
-        const dim3 grid(p.H, p.B, p.n_split), grid2(p.H, p.B);
-        if (dtype == UW_F32) {
-            hipLaunchKernelGGL(cross_decode_split_kernel<float>, grid, dim3(256), lds, s, p);
-            hipLaunchKernelGGL(cross_combine_kernel<float>, grid2, dim3(256), 0, s, p);
-        } else {
-            hipLaunchKernelGGL(cross_decode_split_kernel<bf16_t>, grid, dim3(256), lds, s, p);
-            hipLaunchKernelGGL(cross_combine_kernel<bf16_t>, grid2, dim3(256), 0, s, p);
-        }
+        const dim3 grid(p.H, p.B, p.n_split);
+        if (dtype == UW_F32) hipLaunchKernelGGL(cross_decode_split_kernel<float>, grid, dim3(256), lds, s, p);
+        else hipLaunchKernelGGL(cross_decode_split_kernel<bf16_t>, grid, dim3(256), lds, s, p);
         UW_LAUNCH_CHECK();
         return UW_OK;
     }
@@ -579,22 +603,24 @@ int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s)
     UW_REQUIRE(p.qkv && p.kcache && p.vcache && p.out && p.pos && p.B > 0 && p.H > 0 && p.d == p.H * 64 && p.n_ctx <= 512 && p.ld_cache >= 64,
                "self_attn_decode: bad arguments");
     const dim3 grid(p.H, p.B);
+#define UW_SELF_LAUNCH(T, NU) hipLaunchKernelGGL((self_decode_kernel<T, NU>), grid, dim3(256), 0, s, p)
     if (dtype == UW_F32) {
-        hipLaunchKernelGGL((self_decode_kernel<float, 0>), grid, dim3(256), 0, s, p);
+        UW_SELF_LAUNCH(float, 0);
     } else {
         // bf16: one round of NU loads per lane covers NU * 32 rows; max_rows bounds pos + 1 over the windows of the call
         const int rows = p.max_rows > 0 ? std::min(p.max_rows, p.n_ctx) : p.n_ctx;
         const int nu = (rows + 31) / 32;
         // a grid that fills the chip several times over is bandwidth-bound and runs faster with the short rounds
         // (measured at 128 windows x 12 heads: 18.4 us against 19.6 us per launch)
-        if (p.H * p.B >= 512) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 0>), grid, dim3(256), 0, s, p);
-        else if (nu <= 4) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 4>), grid, dim3(256), 0, s, p);
-        else if (nu <= 6) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 6>), grid, dim3(256), 0, s, p);
-        else if (nu <= 8) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 8>), grid, dim3(256), 0, s, p);
-        else if (nu <= 10) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 10>), grid, dim3(256), 0, s, p);
-        else if (nu <= 12) hipLaunchKernelGGL((self_decode_kernel<bf16_t, 12>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((self_decode_kernel<bf16_t, 14>), grid, dim3(256), 0, s, p);
+        if (p.H * p.B >= 512) UW_SELF_LAUNCH(bf16_t, 0);
+        else if (nu <= 4) UW_SELF_LAUNCH(bf16_t, 4);
+        else if (nu <= 6) UW_SELF_LAUNCH(bf16_t, 6);
+        else if (nu <= 8) UW_SELF_LAUNCH(bf16_t, 8);
+        else if (nu <= 10) UW_SELF_LAUNCH(bf16_t, 10);
+        else if (nu <= 12) UW_SELF_LAUNCH(bf16_t, 12);
+        else UW_SELF_LAUNCH(bf16_t, 14);
     }
+#undef UW_SELF_LAUNCH
     UW_LAUNCH_CHECK();
     return UW_OK;
 }
@@ -602,7 +628,7 @@ int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s)
 int uw_greedy_next(int dtype, const GreedyState& st, const float* logits, long ld, int B, int V, int eot, int sot, int ts_begin,
                    int ts_end, float* x, const float* tok_emb, const float* pos_emb, int d, hipStream_t s)
 {
-    UW_REQUIRE(logits && x && tok_emb && pos_emb && B > 0 && d % 4 == 0, "greedy_next: bad arguments");
+    UW_REQUIRE(logits && x && tok_emb && pos_emb && B > 0 && d % 4 == 0 && d <= 4096, "greedy_next: bad arguments");
     if (dtype == UW_F32)
         hipLaunchKernelGGL(greedy_next_kernel<float>, dim3(B), dim3(1024), 0, s, st, logits, ld, V, eot, sot, ts_begin, ts_end, x, tok_emb, pos_emb, d);
     else

@@ -154,8 +154,9 @@ struct CrossDecodeParams {
     const int32_t* active = nullptr;
     int sel_slot[32];          // per head: slot in [n_sel] or -1
     long ld_kv = 0;            // row stride of K and V (elements)
-    int n_split = 1;           // > 1: the S rows of a (window, head) are cut over n_split workgroups + a combine pass
+    int n_split = 1;           // > 1: the S rows of a (window, head) are cut over n_split workgroups; the last one to finish merges
     float* split_ws = nullptr; // [B][H][n_split][66] partial (max, sum, 64 accumulators), needed when n_split > 1
+    int32_t* split_ticket = nullptr;  // [B][H], zero before the launch and zero again after it, needed when n_split > 1
     long kv_sB = 0, kv_sH = 0; // window and head strides of K and V (elements)
     int B = 0, H = 0, d = 0, S = 0, n_rows_max = 0;
 };
