@@ -258,3 +258,35 @@ def test_cross_attention_decode_forms_agree(micro):
         assert toks[0, : len(new)].tolist() == new
         assert np.abs(rows - got["0"][2]).max() < 1e-6
         assert np.abs(rows[0, :, : len(text)] - np.stack([rows_ref[l][0, h] for l, h in HEADS])).max() < 1e-6
+
+
+def test_weight_prefetch_changes_no_result(micro):
+    """Decode-step products may carry extra workgroups that request the following product's weights (used up to 32
+    windows by default).  They compute nothing: tokens, logits-derived rows and counters are bit-identical with the
+    prefetch forced on and off, for one row of workgroups (2 windows) and several (40 windows, padded grids), in both
+    compute types."""
+    import os
+    enc = micro["enc"]
+    sp = dict(MICRO_SPECIALS, sot=700)
+    base = [[824, 825, 826, 924], [823, 5, 6, 7, 824, 825, 826, 924, 11, 12]]
+    for dtype in ("f32", "bf16"):
+        for B in (2, 40):
+            prompts = [base[i % 2] for i in range(B)]
+            enc_b = torch.from_numpy(np.concatenate([enc[i % 2: i % 2 + 1] for i in range(B)])).to(DEV)
+            got = {}
+            for mode in ("0", "1"):
+                os.environ["UW_STEP_PREFETCH"] = mode
+                try:
+                    eng = E.Engine(micro["dims"], micro["sd"], dtype=dtype, max_batch=B, align_heads=HEADS)
+                finally:
+                    del os.environ["UW_STEP_PREFETCH"]
+                try:
+                    eng.cross_kv(B, enc_b)
+                    res = eng.decode_greedy(prompts, 30, sp["eot"], sp["sot"], sp["ts_begin"], sp["ts_end"])
+                    nt = res["n_text"].cpu().numpy()
+                    got[mode] = (res["new_tokens"].cpu().numpy(), nt, eng.attn_rows(B, int(nt.max())).cpu().numpy())
+                finally:
+                    eng.close()
+            for a, b in zip(got["0"], got["1"]):
+                assert np.array_equal(a, b), (dtype, B)
+            assert got["1"][1].max() > 0

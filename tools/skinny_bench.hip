@@ -7,8 +7,21 @@
 #include <vector>
 void uw_set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+// SK_TOUCH=1: before every product a kernel touches one dword per 128-byte line of the weights it is about to read, workgroup c
+// the block workgroup c of the product will read (same XCD); SK_TOUCH=2: the block of workgroup c + 1 (another XCD, so the
+// lines can only be found in the memory-side cache).  Read the product's duration from a kernel trace.
+__global__ void touch_kernel(const char* w, int block_bytes, int blocks, int shift, int never, unsigned* sink)
+{
+    const int c = (blockIdx.x + shift) % blocks;
+    unsigned v = 0;
+    for (int l = threadIdx.x; l * 128 < block_bytes; l += blockDim.x) v |= *(const unsigned*)(w + (size_t)c * block_bytes + (size_t)l * 128);
+    if (never) sink[threadIdx.x] = v;
+}
+
 int main(int argc, char** argv)
 {
+    const int touch = getenv("SK_TOUCH") ? atoi(getenv("SK_TOUCH")) : 0;
+    const int touch_nt = getenv("SK_TOUCH_NT") ? atoi(getenv("SK_TOUCH_NT")) : 2;   // column tiles per workgroup of the product
     const int M = argc > 1 ? atoi(argv[1]) : 128;
     const int d = argc > 2 ? atoi(argv[2]) : 768;
     struct Shape { int K, N, ln, act, res; const char* name; } shapes[] = {
@@ -19,7 +32,7 @@ int main(int argc, char** argv)
     double total = 0;
     for (auto& sh : shapes) {
         const size_t wbytes = (size_t)sh.N * sh.K * 2;
-        const int copies = (int)((600u << 20) / wbytes) + 1;
+        const int copies = getenv("SK_COPIES") ? atoi(getenv("SK_COPIES")) : (int)((600u << 20) / wbytes) + 1;   // SK_COPIES=1: warm weights
         char *W, *A, *A2; float *C, *bias; char* C2;
         const size_t abytes = (size_t)((M + 15) & ~15) * sh.K * 4;
         CK(hipMalloc(&W, wbytes * copies)); CK(hipMalloc(&A, abytes)); CK(hipMalloc(&A2, abytes)); CK(hipMalloc(&C, (size_t)128 * sh.N * 4)); CK(hipMalloc(&C2, (size_t)128 * sh.N * 4));
@@ -35,6 +48,10 @@ int main(int argc, char** argv)
             if (rep == 1) CK(hipEventRecord(e0, s));
             for (int i = 0; i < iters; ++i) {
                 p.B = W + (size_t)(i % copies) * wbytes;
+                if (touch) {
+                    const int bb = touch_nt * 16 * sh.K * 2, blocks = sh.N / (touch_nt * 16);
+                    hipLaunchKernelGGL(touch_kernel, dim3(blocks), dim3(512), 0, s, (const char*)p.B, bb, blocks, touch == 2 ? 1 : 0, 0, (unsigned*)C2);
+                }
                 if (uw_gemm_skinny(UW_BF16, out_f32, p, s)) return 1;
             }
         }

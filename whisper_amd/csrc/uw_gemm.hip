@@ -790,6 +790,51 @@ constexpr int SK_WAVES = 8;
 constexpr int SK_ROUND = 3;      // K-steps per register buffer; two buffers are in flight
 constexpr int SK_ROUND_LN = 2;   // same for the LayerNorm-fused form, whose f32 operand takes twice the registers
 
+// Workgroup `i` of the extra ones a launch carries for GemmParams::pf: requests one dword of every 128-byte line of the
+// weight block that workgroup (i - pf_shift) of the following launch will read.  pf_shift makes the two land on the
+// same XCD (workgroups are dealt to the 8 XCDs round-robin by their linear index).  Nothing is kept: the lines stay
+// behind in that XCD's L2.  pf_never is always 0; the store under it only keeps the loads alive.
+template <typename T>
+__device__ __forceinline__ void prefetch_following_weights(const GemmParams& p, int i)
+{
+    const int c = i - p.pf_shift, blocks = (p.pf_n + p.pf_cols - 1) / p.pf_cols;
+    if (blockIdx.y != 0 || c < 0 || c >= blocks) return;
+    const long rows16 = (p.pf_n + 15) >> 4, first16 = (long)c * (p.pf_cols >> 4);
+    const long bytes16 = (long)p.pf_k * 16 * (long)sizeof(T);                        // one 16-row block of the packed matrix
+    const long lines = min((long)(p.pf_cols >> 4), rows16 - first16) * bytes16 / 128;
+    const char* base = (const char*)p.pf + first16 * bytes16;
+    unsigned v = 0;
+    for (long l0 = threadIdx.x; l0 < lines; l0 += 8 * (long)blockDim.x) {
+        unsigned t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long l = l0 + u * (long)blockDim.x;
+            t[u] = l < lines ? *(const unsigned*)(base + l * 128) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v |= t[u];
+    }
+    if (p.pf_never) *(unsigned*)p.C = v;
+}
+
+// grid of a skinny launch: the extra workgroups of GemmParams::pf are appended along x, and with several rows of
+// workgroups the row length is padded to a multiple of 8, so that block c of this launch is read from XCD c % 8 in
+// every row (which is where the launch before it left it)
+static dim3 grid_with_prefetch(GemmParams& q, int gx, int gy)
+{
+    q.pf_first = gx;
+    q.pf_never = 0;
+    int extra = 0;
+    if (q.pf && q.pf_cols >= 16 && q.pf_n > 0 && q.pf_k > 0) {
+        q.pf_shift = (8 - gx % 8) % 8;      // extra workgroup i has linear index gx + i: on the XCD of block i - pf_shift
+        extra = q.pf_shift + (q.pf_n + q.pf_cols - 1) / q.pf_cols;
+    } else {
+        q.pf = nullptr;
+    }
+    if (gy > 1) extra += (8 - (gx + extra) % 8) % 8;
+    return dim3(gx + extra, gy);
+}
+
 // HILO: A arrives as two fragment-major planes, hi and lo (split activations, see GemmParams); every weight block is
 // multiplied with both, the matrix cores being idle in this kernel anyway.
 template <typename T, typename TC, int MT, int NT, bool PACKED, bool HILO = false>
@@ -799,6 +844,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_skinny_kernel(GemmParams p
     constexpr int E = 16 / (int)sizeof(T);
     constexpr int KS = 4 * E;                 // K elements per step (one MFMA chunk group)
     f32x4* part = (f32x4*)smem;               // [SK_WAVES][MT * NT][64]
+    if ((int)blockIdx.x >= p.pf_first) {
+        if (p.pf) prefetch_following_weights<T>(p, (int)blockIdx.x - p.pf_first);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: K offsets stay scalar
     const int fr = lane & 15, fg = lane >> 4;
@@ -966,6 +1015,10 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_step_ln_kernel(GemmParams 
     f32x4* part = (f32x4*)smem;                          // [SK_WAVES][MT * NT][64]
     float* stat = (float*)(part + SK_WAVES * MT * NT * 64);   // [SK_WAVES][MT][16][2]
     float* gam = stat + SK_WAVES * MT * 16 * 2;               // [K] LayerNorm scale
+    if ((int)blockIdx.x >= p.pf_first) {
+        if (p.pf) prefetch_following_weights<T>(p, (int)blockIdx.x - p.pf_first);
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
@@ -1160,9 +1213,10 @@ __global__ void pack_frag_kernel(const T* __restrict__ src, long ld, T* __restri
 template <typename T, typename TC, int MT, int NT> int launch_skinny_mt(const GemmParams& p, hipStream_t s)
 {
     const size_t lds = (size_t)SK_WAVES * MT * NT * 64 * sizeof(f32x4);
-    const dim3 grid((p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
-    if (p.ab_packed) hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT, NT, true>), grid, dim3(64 * SK_WAVES), lds, s, p);
-    else hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT, NT, false>), grid, dim3(64 * SK_WAVES), lds, s, p);
+    GemmParams q = p;
+    const dim3 grid = grid_with_prefetch(q, (p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
+    if (p.ab_packed) hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT, NT, true>), grid, dim3(64 * SK_WAVES), lds, s, q);
+    else hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT, NT, false>), grid, dim3(64 * SK_WAVES), lds, s, q);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }
@@ -1170,8 +1224,9 @@ template <typename T, typename TC, int MT, int NT> int launch_skinny_mt(const Ge
 template <typename T, typename TC, int MT, int NT> int launch_skinny_hilo(const GemmParams& p, hipStream_t s)
 {
     const size_t lds = (size_t)SK_WAVES * MT * NT * 64 * sizeof(f32x4);
-    const dim3 grid((p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
-    hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT, NT, true, true>), grid, dim3(64 * SK_WAVES), lds, s, p);
+    GemmParams q = p;
+    const dim3 grid = grid_with_prefetch(q, (p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
+    hipLaunchKernelGGL((gemm_skinny_kernel<T, TC, MT, NT, true, true>), grid, dim3(64 * SK_WAVES), lds, s, q);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }
@@ -1179,15 +1234,35 @@ template <typename T, typename TC, int MT, int NT> int launch_skinny_hilo(const 
 template <typename T, typename TC, int MT, int NT> int launch_step_ln_mt(const GemmParams& p, hipStream_t s)
 {
     const size_t lds = (size_t)SK_WAVES * MT * NT * 64 * sizeof(f32x4) + (size_t)SK_WAVES * MT * 16 * 2 * sizeof(float) + (size_t)p.K * sizeof(float);
-    const dim3 grid((p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
+    GemmParams q = p;
+    const dim3 grid = grid_with_prefetch(q, (p.N + NT * 16 - 1) / (NT * 16), (p.M + MT * 16 - 1) / (MT * 16));
     static PerDeviceFlag attr_set;
     if (lds > 64 * 1024 && attr_set.pending()) {
         UW_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_step_ln_kernel<T, TC, MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set.mark();
     }
-    hipLaunchKernelGGL((gemm_step_ln_kernel<T, TC, MT, NT>), grid, dim3(64 * SK_WAVES), lds, s, p);
+    hipLaunchKernelGGL((gemm_step_ln_kernel<T, TC, MT, NT>), grid, dim3(64 * SK_WAVES), lds, s, q);
     UW_LAUNCH_CHECK();
     return UW_OK;
+}
+
+// 16-column tiles per workgroup of the LayerNorm-fused form.  Measured at M = 128, K = 768: 16 rows x 48 columns per
+// workgroup for the wide products (6.8 / 7.5 us at N = 2304 / 3072 against 7.6 / 8.2 us with 32 x 64), 16 x 32 for
+// N = K, which is also best for 32 rows at every width tried (512, 768, 1280)
+static int step_ln_column_tiles(int M, int N)
+{
+    if (M <= 16) return N >= 2048 ? 2 : 1;
+    return (N >= 2048 && M > 64) ? 3 : 2;
+}
+// ... of the split-activation form: up to 32 rows 16 x 16 tiles are fastest (the grid is still under one workgroup per
+// CU); at M = 128 16 rows x 32 columns beats 32 x 16 by 8-11 %
+static int hilo_column_tiles(int M) { return M <= 64 ? 1 : 2; }
+// ... of the plain form: few rows per workgroup keep its activation traffic small; wide N takes more tiles per
+// workgroup so the grid stays near one workgroup per CU
+static int plain_column_tiles(int M, int N)
+{
+    if (M <= 16) return N >= 2048 ? 2 : 1;
+    return (N >= 2048 && M > 32) ? 2 : 1;
 }
 
 template <typename T, typename TC> int launch_step_ln(const GemmParams& p, hipStream_t s)
@@ -1215,11 +1290,10 @@ template <typename T, typename TC> int launch_step_ln(const GemmParams& p, hipSt
         if (t == 42) return launch_step_ln_mt<T, TC, 4, 2>(p, s);
     }
 #endif
-    if (p.M <= 16) return p.N >= 2048 ? launch_step_ln_mt<T, TC, 1, 2>(p, s) : launch_step_ln_mt<T, TC, 1, 1>(p, s);
-    // measured at M = 128, K = 768: 16 rows x 48 columns per workgroup for the wide products (6.8 / 7.5 us at N = 2304 /
-    // 3072 against 7.6 / 8.2 us with 32 x 64), 16 x 32 for N = K
-    if (p.N >= 2048 && p.M > 64) return launch_step_ln_mt<T, TC, 1, 3>(p, s);
-    return launch_step_ln_mt<T, TC, 1, 2>(p, s);     // also best for 32 rows at every width tried (512, 768, 1280)
+    const int nt = step_ln_column_tiles(p.M, p.N);
+    if (nt == 1) return launch_step_ln_mt<T, TC, 1, 1>(p, s);
+    if (nt == 3) return launch_step_ln_mt<T, TC, 1, 3>(p, s);
+    return launch_step_ln_mt<T, TC, 1, 2>(p, s);
 }
 
 template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStream_t s)
@@ -1252,22 +1326,26 @@ template <typename T, typename TC> int launch_skinny(const GemmParams& p, hipStr
                 if (t == 41) return launch_skinny_hilo<T, TC, 4, 1>(p, s);
             }
 #endif
-            // measured: up to 32 rows 16 x 16 tiles are fastest (the grid is still under one workgroup per CU); at M = 128
-            // 16 rows x 32 columns beats 32 x 16 by 8-11 %
-            if (p.M <= 64) return launch_skinny_hilo<T, TC, 1, 1>(p, s);
+            if (hilo_column_tiles(p.M) == 1) return launch_skinny_hilo<T, TC, 1, 1>(p, s);
             return launch_skinny_hilo<T, TC, 1, 2>(p, s);
         } else {
             UW_REQUIRE(false, "skinny gemm: split A is a bf16 form");
         }
     }
-    // 16 x 16 output tiles per workgroup: few rows per workgroup keep its activation traffic small; wide N takes
-    // more tiles per workgroup so the grid stays near one workgroup per CU
-    if (p.M <= 16) return p.N >= 2048 ? launch_skinny_mt<T, TC, 1, 2>(p, s) : launch_skinny_mt<T, TC, 1, 1>(p, s);
-    if (p.N >= 2048 && p.M > 32) return launch_skinny_mt<T, TC, 4, 2>(p, s);
+    const int nt = plain_column_tiles(p.M, p.N);
+    if (p.M <= 16) return nt == 2 ? launch_skinny_mt<T, TC, 1, 2>(p, s) : launch_skinny_mt<T, TC, 1, 1>(p, s);
+    if (nt == 2) return launch_skinny_mt<T, TC, 4, 2>(p, s);
     return launch_skinny_mt<T, TC, 2, 1>(p, s);
 }
 
 }  // namespace
+
+int uw_gemm_skinny_block_columns(int dtype, int M, int N, int ln_fused, int hilo)
+{
+    if (ln_fused) return 16 * step_ln_column_tiles(M, N);
+    if (hilo && dtype == UW_BF16) return 16 * hilo_column_tiles(M);
+    return 16 * plain_column_tiles(M, N);
+}
 
 int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s)
 {

@@ -50,7 +50,17 @@ struct GemmParams {
     void* C_lo = nullptr;
     long c_group = 0;   // 0: C[m][n] at m*ldc + n.  Else columns are stored in groups of 64 (one attention head):
                         // C[m][n] at (n / 64) * c_group + m * ldc + (n % 64), ldc = 64 for a head-contiguous cache
+    // Skinny form: fragment-major weights [pf_n][pf_k] of the product that FOLLOWS this one in the decode step (or null).
+    // The launch then carries extra workgroups that only request those weights, each the block that the workgroup of the
+    // following launch scheduled on the same XCD will read, so that product finds its weights in that XCD's L2 instead of
+    // fetching them from HBM after it has started.  pf_cols: output columns per workgroup of the following launch
+    // (uw_gemm_skinny_block_columns).  pf_first / pf_shift / pf_never are filled in by the launcher.
+    const void* pf = nullptr;
+    int pf_n = 0, pf_k = 0, pf_cols = 0;
+    int pf_first = 0x7fffffff, pf_shift = 0, pf_never = 0;   // pf_first: workgroups from this x index on compute nothing
 };
+// output columns per workgroup that uw_gemm_skinny picks for a product of M rows and N columns (hilo: split A planes)
+int uw_gemm_skinny_block_columns(int dtype, int M, int N, int ln_fused, int hilo);
 // dtype: element type of A and B.  out_f32: C is f32 even when dtype is bf16 (always f32 for UW_F32).
 int uw_gemm(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
 // M <= 128, batch 1: weight-streaming form for the decode step.  With p.ab_packed both A and B are in the
