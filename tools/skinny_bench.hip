@@ -48,6 +48,10 @@ int main(int argc, char** argv)
             if (rep == 1) CK(hipEventRecord(e0, s));
             for (int i = 0; i < iters; ++i) {
                 p.B = W + (size_t)(i % copies) * wbytes;
+                if (getenv("SK_PF")) {   // the launch requests the weights of the next one (GemmParams::pf)
+                    p.pf = W + (size_t)((i + 1) % copies) * wbytes; p.pf_n = sh.N; p.pf_k = sh.K;
+                    p.pf_cols = uw_gemm_skinny_block_columns(UW_BF16, M, sh.N, sh.ln, sh.ln ? 0 : 1);
+                }
                 if (touch) {
                     const int bb = touch_nt * 16 * sh.K * 2, blocks = sh.N / (touch_nt * 16);
                     hipLaunchKernelGGL(touch_kernel, dim3(blocks), dim3(512), 0, s, (const char*)p.B, bb, blocks, touch == 2 ? 1 : 0, 0, (unsigned*)C2);
