@@ -80,7 +80,8 @@ class ResultExchange:
         for (k, shape, _), w in zip(self._layout, self._widths):
             self._send[:n, col:col + w].copy_(local[k].reshape(n, w))
             col += w
-        dist.all_gather(list(self._recv.unbind(0)), self._send)
+        # one collective into one contiguous buffer: neither backend needs a staging copy or an allocation for it
+        dist.all_gather_into_tensor(self._recv.view(self.world * self.most, -1), self._send)
         self.collectives += 1
         rows = torch.cat([self._recv[r, : self.counts[r]] for r in range(self.world)], dim=0)
         out, col = {}, 0
