@@ -290,3 +290,36 @@ def test_weight_prefetch_changes_no_result(micro):
             for a, b in zip(got["0"], got["1"]):
                 assert np.array_equal(a, b), (dtype, B)
             assert got["1"][1].max() > 0
+
+
+def test_one_launch_logits_agree_with_separate_kernels(micro):
+    """Up to 16 windows in bf16, a decode step produces its logits in one launch (final LayerNorm, tied projection and
+    per-block arg-max candidates, uw_logits_rows16) instead of LayerNorm + projection + a scan of the row.  Both forms:
+    step logits within 2e-3 of each other (the LayerNorm is evaluated in a different order), the arg-max of every row
+    found through the candidates equals the arg-max of the stored logits, and greedy decoding gives the same tokens."""
+    import os
+    enc = micro["enc"]
+    sp = dict(MICRO_SPECIALS, sot=700)
+    base = [[824, 825, 826, 924], [823, 5, 6, 7, 824, 825, 826, 924, 11, 12]]
+    for B in (1, 3, 16):
+        prompts = [base[i % 2] for i in range(B)]
+        enc_b = torch.from_numpy(np.concatenate([enc[i % 2: i % 2 + 1] for i in range(B)])).to(DEV)
+        got = {}
+        for mode in ("0", "1"):
+            os.environ["UW_LOGITS_FUSED"] = mode
+            try:
+                eng = E.Engine(micro["dims"], micro["sd"], dtype="bf16", max_batch=B, align_heads=HEADS)
+            finally:
+                del os.environ["UW_LOGITS_FUSED"]
+            try:
+                eng.cross_kv(B, enc_b)
+                ids = torch.tensor([p[0] for p in prompts], dtype=torch.int32)
+                logits = eng.decode_step(ids, torch.zeros(B, dtype=torch.int32)).cpu().numpy()
+                res = eng.decode_greedy(prompts, 30, sp["eot"], sp["sot"], sp["ts_begin"], sp["ts_end"])
+                got[mode] = (logits, res["new_tokens"].cpu().numpy(), res["n_new"].cpu().numpy())
+            finally:
+                eng.close()
+        assert np.isfinite(got["1"][0]).all()
+        assert np.abs(got["0"][0] - got["1"][0]).max() < 2e-3, (B, np.abs(got["0"][0] - got["1"][0]).max())
+        assert np.array_equal(got["0"][1], got["1"][1]) and np.array_equal(got["0"][2], got["1"][2]), B
+        assert got["1"][2].max() > 0

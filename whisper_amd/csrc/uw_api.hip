@@ -63,6 +63,7 @@ struct uw_ctx {
     // decoder weights
     float *tok_emb32 = nullptr, *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
     void* tok_emb = nullptr;   // [V][d] compute dtype (tied output projection)
+    void* tok_emb_p = nullptr; // bf16 contexts of up to 16 windows: the same, fragment-major (the one-launch logits form streams it)
     // alignment heads
     int n_sel = 0;
     // workspace: encoder
@@ -106,6 +107,9 @@ struct uw_ctx {
     float* split_ws = nullptr;
     int32_t* split_ticket = nullptr;   // [Bm][H] arrival counters of the row-split cross-attention (zero between launches)
     int step_prefetch = -1;        // decode-step products request the following product's weights: -1 by row count, 0 never, 1 always
+    int fused_logits = 1;          // up to 16 windows (bf16): LayerNorm + tied projection + arg-max candidates in one launch
+    float* cand_val = nullptr;     // [Bm rounded up to 16][uw_logits_rows16_blocks(V)] arg-max candidates of the step's logits
+    int32_t* cand_idx = nullptr;
 };
 
 namespace {
@@ -261,6 +265,10 @@ int load_weights(uw_ctx* c, const void* const* weights, int n_weights)
     } else {
         ALLOC(c->tok_emb, (long)c->V * d * c->es, false);
         RUN(pack_rows(c, c->tok_emb, 0, temb, c->V, d, 1.f));
+        if (c->Bm <= 16 && d % 32 == 0 && d <= 1280) {
+            ALLOC(c->tok_emb_p, (long)((c->V + 15) & ~15) * d * c->es, false);
+            RUN(uw_pack_frag(c->dt, c->tok_emb, d, c->tok_emb_p, c->V, (int)d, 0));
+        }
     }
     c->dec.resize(g.dec_layers);
     for (auto& l : c->dec) {
@@ -340,6 +348,8 @@ int create_streams(uw_ctx* c)
     if (c->split_mode > 16) c->split_mode = 16;
     const char* pfw = getenv("UW_STEP_PREFETCH");   // development / test knob
     c->step_prefetch = pfw ? atoi(pfw) : -1;
+    const char* fl = getenv("UW_LOGITS_FUSED");     // development / test knob
+    c->fused_logits = fl ? atoi(fl) : 1;
     c->n_streams = env ? atoi(env) : 1;   // concurrent queues did not overlap on MI355X (measured): one stream by default
     if (c->n_streams < 1) c->n_streams = 1;
     if (c->n_streams > 4) c->n_streams = 4;
@@ -382,6 +392,8 @@ int alloc_workspace(uw_ctx* c)
     ALLOC(c->d_last, ((Bm + 15) & ~15l) * d * 4, true);
     ALLOC(c->split_ws, Bm * (d / 64) * 16 * 66 * 4, true);
     ALLOC(c->split_ticket, Bm * (d / 64) * 4, true);
+    ALLOC(c->cand_val, ((Bm + 15) & ~15l) * uw_logits_rows16_blocks(c->V) * 4, true);
+    ALLOC(c->cand_idx, ((Bm + 15) & ~15l) * uw_logits_rows16_blocks(c->V) * 4, true);
     c->logits_ld = (c->V + 3) & ~3;
     ALLOC(c->logits, Bm * c->logits_ld * 4, true);
     if (c->n_sel > 0) {
@@ -707,19 +719,22 @@ __global__ void embed_step_kernel(float* __restrict__ x, const float* __restrict
     for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) *(f32x4*)(x + x_elem_offset<T>(b, i * 4, d)) = e[i] + pe[i];
 }
 
-int decoder_step_chunk(uw_ctx* c, int b0, int B, bool embed, hipStream_t s);
+int decoder_step_chunk(uw_ctx* c, int b0, int B, bool embed, bool greedy, hipStream_t s);
+// a step over at most 16 windows takes the one-launch logits form (uw_logits_rows16), which also leaves arg-max candidates
+bool step_uses_rows16(const uw_ctx* c, int B) { return c->fused_logits && c->tok_emb_p && B <= 16; }
 // one KV-cached decoder step for the token at st_pos[b] of windows [b0, b0 + B) -> their rows of c->logits.
 // The step's products take at most 128 rows per launch: larger batches go through in chunks of 128 windows.
 // embed: build the residual-stream rows from st_tokens / st_pos first (the greedy loop's later steps get them from
-// the previous step's uw_greedy_next instead)
-int decoder_step(uw_ctx* c, int b0, int B, bool embed, hipStream_t s)
+// the previous step's uw_greedy_next instead).  greedy: the caller is the greedy loop; where the step leaves arg-max
+// candidates (step_uses_rows16) it reads those and the logits themselves are not stored
+int decoder_step(uw_ctx* c, int b0, int B, bool embed, hipStream_t s, bool greedy = false)
 {
-    for (int off = 0; off < B; off += 128) RUN(decoder_step_chunk(c, b0 + off, std::min(128, B - off), embed, s));
+    for (int off = 0; off < B; off += 128) RUN(decoder_step_chunk(c, b0 + off, std::min(128, B - off), embed, greedy, s));
     return UW_OK;
 }
 
 // Every buffer is indexed by window, so disjoint window ranges (starting on multiples of 16) are independent.
-int decoder_step_chunk(uw_ctx* c, int b0, int B, bool embed, hipStream_t s)
+int decoder_step_chunk(uw_ctx* c, int b0, int B, bool embed, bool greedy, hipStream_t s)
 {
     const int d = c->d, S = c->S, H = c->H, Tm = c->Tm;
     const size_t es = c->es;
@@ -786,6 +801,15 @@ int decoder_step_chunk(uw_ctx* c, int b0, int B, bool embed, hipStream_t s)
         RUN(gemm_step(c, att, att_lo, l.cross.wo_p, x, d, true, B, d, d, l.cross.bo, 0, x, d, false, s, &n_fc1));
         RUN(gemm_step_ln(c, x, l.w1_p, l.ln2_g, l.b1ln, l.w1sum, mlp, 4 * d, B, 4 * d, d, 1, true, s, mlp_lo, false, &n_fc2));
         RUN(gemm_step(c, mlp, mlp_lo, l.w2_p, x, d, true, B, d, 4 * d, l.b2, 0, x, d, false, s, &n_qkv));
+    }
+    if (step_uses_rows16(c, B)) {
+        LogitsRows16Params lp;
+        lp.x = x; lp.gamma = c->dec_ln_g; lp.beta = c->dec_ln_b; lp.W = c->tok_emb_p;
+        lp.logits = greedy ? nullptr : logits; lp.ldl = c->logits_ld;
+        const long n_blk = uw_logits_rows16_blocks(c->V);
+        lp.cand_val = c->cand_val + (long)b0 * n_blk; lp.cand_idx = c->cand_idx + (long)b0 * n_blk;
+        lp.M = B; lp.V = c->V; lp.d = d;
+        return uw_logits_rows16(lp, s);
     }
     return logits_from_x(c, x, B, (char*)c->d_ln + (size_t)b0 * 2 * d * es, logits, s);
 }
@@ -1140,9 +1164,12 @@ int uw_decode_greedy(uw_ctx* c, const int32_t* prompt_ids, int ld_prompt, const 
                 sk.n_active = c->st_n_active + k;
                 c->step_rows = std::min(c->Tm, Pmax + step);   // the longest prompt's position + 1 at this step
                 const int step_slot = span_begin(c, 4, 8, ss[k]);
-                RUN(decoder_step(c, b0, Bn, step == 0, ss[k]));
+                RUN(decoder_step(c, b0, Bn, step == 0, ss[k], true));
+                const bool cand = step_uses_rows16(c, Bn);
+                const long n_blk = uw_logits_rows16_blocks(c->V);
                 RUN(uw_greedy_next(c->dt, sk, c->logits + (long)b0 * c->logits_ld, c->logits_ld, Bn, c->V, eot, sot, ts_begin, ts_end,
-                                   c->d_x + (long)b0 * c->d, c->tok_emb32, c->dec_pos, c->d, ss[k]));
+                                   c->d_x + (long)b0 * c->d, c->tok_emb32, c->dec_pos, c->d, ss[k], cand ? c->cand_val + (long)b0 * n_blk : nullptr,
+                                   cand ? c->cand_idx + (long)b0 * n_blk : nullptr, (int)n_blk));
                 span_end(c, 4, step_slot, ss[k]);
                 if ((step & 7) == 7 && step + 1 < max_steps) {
                     // non-blocking look at the counter copied 8 steps ago, then queue the next copy

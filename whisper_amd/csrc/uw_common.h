@@ -186,6 +186,25 @@ __device__ __forceinline__ float wave_max(float v)
 // eight independent loads in flight per thread.  sv / si: 16-entry LDS scratch.  The result is valid in thread 0 (after
 // the internal barrier); row must be 16-byte aligned for the vector path.  A NaN never wins the comparison; *any_nan
 // (valid in every thread) tells the caller that the row held one, so it can refuse the row instead of trusting the index.
+// tail of the block-wide arg-max (1024 threads): every thread brings its best (value, index, saw-a-NaN); the first index wins ties
+__device__ __forceinline__ int block_argmax_finish(float best, int arg, bool bad, float* sv, int* si, bool* any_nan)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(arg, o, 64);
+        if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = arg; }
+    const int nan_seen = __syncthreads_or(bad ? 1 : 0);
+    if (any_nan) *any_nan = nan_seen != 0;
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < arg)) { best = sv[w]; arg = si[w]; }
+    }
+    return (arg == 0x7fffffff) ? 0 : arg;
+}
+
 __device__ __forceinline__ int block_argmax_1024(const float* __restrict__ row, int V, float* sv, int* si, bool* any_nan = nullptr)
 {
     float best = -INFINITY;
@@ -207,20 +226,23 @@ __device__ __forceinline__ int block_argmax_1024(const float* __restrict__ row, 
             for (int k = 0; k < 4; ++k) take(v[u][k], (i0 + u * 1024) * 4 + k);
     }
     for (int i = V4 * 4 + threadIdx.x; i < V; i += 1024) take(row[i], i);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o, 64);
-        const int oi = __shfl_xor(arg, o, 64);
-        if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }
+    return block_argmax_finish(best, arg, bad, sv, si, any_nan);
+}
+
+// the same over n (value, index) candidates, one per column block of the row (a NaN value marks a block that holds one)
+__device__ __forceinline__ int block_argmax_candidates(const float* __restrict__ val, const int32_t* __restrict__ idx, int n, float* sv,
+                                                       int* si, bool* any_nan = nullptr)
+{
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    bool bad = false;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float v = val[i];
+        const int a = idx[i];
+        bad |= (v != v);
+        if (v > best || (v == best && a < arg)) { best = v; arg = a; }
     }
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = arg; }
-    const int nan_seen = __syncthreads_or(bad ? 1 : 0);
-    if (any_nan) *any_nan = nan_seen != 0;
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w)
-            if (sv[w] > best || (sv[w] == best && si[w] < arg)) { best = sv[w]; arg = si[w]; }
-    }
-    return (arg == 0x7fffffff) ? 0 : arg;
+    return block_argmax_finish(best, arg, bad, sv, si, any_nan);
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

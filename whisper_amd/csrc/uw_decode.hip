@@ -512,7 +512,8 @@ __global__ __launch_bounds__(256) void self_decode_kernel(SelfDecodeParams p)
 template <typename T>
 __global__ __launch_bounds__(1024) void greedy_next_kernel(GreedyState st, const float* __restrict__ logits, long ld, int V, int eot,
                                                            int sot, int ts_begin, int ts_end, float* __restrict__ x,
-                                                           const float* __restrict__ tok_emb, const float* __restrict__ pos_emb, int d)
+                                                           const float* __restrict__ tok_emb, const float* __restrict__ pos_emb, int d,
+                                                           const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx, int n_cand)
 {
     __shared__ float sv[16];
     __shared__ int si[16];
@@ -526,7 +527,9 @@ __global__ __launch_bounds__(1024) void greedy_next_kernel(GreedyState st, const
     f32x4 pe_next = {0.f, 0.f, 0.f, 0.f};
     if ((int)threadIdx.x < (d >> 2)) pe_next = ((const f32x4*)(pos_emb + (long)min(pos0 + 1, n_ctx_rows - 1) * d))[threadIdx.x];
     bool nan_row = false;
-    const int tok = block_argmax_1024(logits + (long)b * ld, V, sv, si, &nan_row);
+    // with candidates (one per 256-column block of the row, left by the logits kernel) the row itself is not read
+    const int tok = cand_val ? block_argmax_candidates(cand_val + (long)b * n_cand, cand_idx + (long)b * n_cand, n_cand, sv, si, &nan_row)
+                             : block_argmax_1024(logits + (long)b * ld, V, sv, si, &nan_row);
     if (threadIdx.x == 0) {
         bool alive = true;
         int idx = -1;
@@ -626,13 +629,17 @@ int uw_self_attn_decode(int dtype, const SelfDecodeParams& p, hipStream_t s)
 }
 
 int uw_greedy_next(int dtype, const GreedyState& st, const float* logits, long ld, int B, int V, int eot, int sot, int ts_begin,
-                   int ts_end, float* x, const float* tok_emb, const float* pos_emb, int d, hipStream_t s)
+                   int ts_end, float* x, const float* tok_emb, const float* pos_emb, int d, hipStream_t s, const float* cand_val,
+                   const int32_t* cand_idx, int n_cand)
 {
-    UW_REQUIRE(logits && x && tok_emb && pos_emb && B > 0 && d % 4 == 0 && d <= 4096, "greedy_next: bad arguments");
+    UW_REQUIRE((logits || cand_val) && x && tok_emb && pos_emb && B > 0 && d % 4 == 0 && d <= 4096, "greedy_next: bad arguments");
+    UW_REQUIRE(!cand_val || (cand_idx && n_cand > 0), "greedy_next: candidate values without indices");
     if (dtype == UW_F32)
-        hipLaunchKernelGGL(greedy_next_kernel<float>, dim3(B), dim3(1024), 0, s, st, logits, ld, V, eot, sot, ts_begin, ts_end, x, tok_emb, pos_emb, d);
+        hipLaunchKernelGGL(greedy_next_kernel<float>, dim3(B), dim3(1024), 0, s, st, logits, ld, V, eot, sot, ts_begin, ts_end, x, tok_emb, pos_emb, d,
+                           cand_val, cand_idx, n_cand);
     else
-        hipLaunchKernelGGL(greedy_next_kernel<bf16_t>, dim3(B), dim3(1024), 0, s, st, logits, ld, V, eot, sot, ts_begin, ts_end, x, tok_emb, pos_emb, d);
+        hipLaunchKernelGGL(greedy_next_kernel<bf16_t>, dim3(B), dim3(1024), 0, s, st, logits, ld, V, eot, sot, ts_begin, ts_end, x, tok_emb, pos_emb, d,
+                           cand_val, cand_idx, n_cand);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }

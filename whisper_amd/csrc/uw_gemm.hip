@@ -758,6 +758,184 @@ __global__ __launch_bounds__(512) void gemm_rows_hilo_kernel(GemmParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Logits of a decode step for at most 16 windows (see LogitsRows16Params).  Against LayerNorm + gemm_rows_hilo_kernel +
+// a scan of the logits this is one launch instead of two, no 128-row tile for a handful of rows, and the greedy step
+// reads one candidate per workgroup and row instead of the whole row.
+// One workgroup = 256 vocabulary columns, 8 waves x two 16-column tiles.  Phase 1: every workgroup normalises the 16
+// rows itself (16 x d floats from L2): wave w takes the 32-column K-steps w, w + 8, ..., a lane holds the 8 columns of
+// its MFMA operand chunk, so the normalised values go to LDS as ready operand blocks, hi and lo plane.  Phase 2: the
+// fragment-major embedding streams from memory straight into registers (1 KiB of consecutive bytes per wave
+// instruction; with row-major rows, 16 x 64 bytes per instruction, the same kernel reached 2.7 TB/s), LR_U K-steps in
+// flight per buffer, two buffers.
+constexpr int LR_WAVES = 8, LR_COLS = 256, LR_U = 6, LR_MAXS = 5;   // LR_MAXS: K-steps per wave in phase 1 (d <= 1280)
+
+__global__ __launch_bounds__(64 * LR_WAVES) void logits_rows16_kernel(LogitsRows16Params p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [d / 32][hi, lo][64 lanes][16 B]
+    __shared__ float stat[LR_WAVES][16][2];
+    __shared__ float c_val[LR_WAVES][16];
+    __shared__ int c_idx[LR_WAVES][16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int steps = p.d >> 5;
+    // the embedding does not depend on the LayerNorm: the first two buffers of the stream are requested before its
+    // arithmetic and arrive while the rows are being normalised
+    const int n0 = blockIdx.x * LR_COLS + wave * 32;
+    const int n_blocks = (p.V + 15) >> 4;
+    const char* wrow[2];        // this lane's 16 bytes of the first operand block of each tile; blocks of a tile follow every 1 KiB
+#pragma unroll
+    for (int t = 0; t < 2; ++t) wrow[t] = (const char*)p.W + ((long)min((n0 >> 4) + t, n_blocks - 1) * steps * 64 + lane) * 16;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    uint4 wv[2][LR_U][2];
+    auto load_round = [&](int buf, int s0) {
+#pragma unroll
+        for (int u = 0; u < LR_U; ++u) {
+            const int st = min(s0 + u, steps - 1);      // steps past the end re-read the last one (unused)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                const u32x4 v = __builtin_nontemporal_load((const u32x4*)(wrow[t] + st * 1024));   // read once per step
+                wv[buf][u][t] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+        }
+    };
+    // ---- phase 1: LayerNorm of the 16 rows into LDS.  Its operand is requested first (loads return in order), the
+    // stream right behind it.
+    {
+        f32x4 xv[LR_MAXS][2];
+#pragma unroll
+        for (int i = 0; i < LR_MAXS; ++i) {
+            const int st = min(wave + LR_WAVES * i, steps - 1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) xv[i][h] = *(const f32x4*)(p.x + ((long)(st * 2 + h) * 64 + lane) * 4);
+        }
+        load_round(0, 0);
+        if (LR_U < steps) load_round(1, LR_U);
+        __builtin_amdgcn_sched_barrier(0);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LR_MAXS; ++i) {
+            if (wave + LR_WAVES * i < steps) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 v = xv[i][h];
+                    s1 += (v[0] + v[1]) + (v[2] + v[3]);
+                    s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+            }
+        }
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (fg == 0) { stat[wave][fr][0] = s1; stat[wave][fr][1] = s2; }
+        __syncthreads();
+        float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < LR_WAVES; ++w) { S1 += stat[w][fr][0]; S2 += stat[w][fr][1]; }
+        const float inv_d = 1.0f / (float)p.d;
+        const float mean = S1 * inv_d;
+        const float rstd = 1.0f / sqrtf(fmaxf(S2 * inv_d - mean * mean, 0.f) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < LR_MAXS; ++i) {
+            const int st = wave + LR_WAVES * i;
+            if (st < steps) {
+                union { bf16_t h[8]; uint4 u; } hi, lo;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 g = *(const f32x4*)(p.gamma + st * 32 + fg * 8 + h * 4), b = *(const f32x4*)(p.beta + st * 32 + fg * 8 + h * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = (xv[i][h][e] - mean) * rstd * g[e] + b[e];
+                        hi.h[h * 4 + e] = (bf16_t)y;
+                        lo.h[h * 4 + e] = (bf16_t)(y - (float)hi.h[h * 4 + e]);
+                    }
+                }
+                *(uint4*)(smem + ((st * 2 + 0) * 64 + lane) * 16) = hi.u;
+                *(uint4*)(smem + ((st * 2 + 1) * 64 + lane) * 16) = lo.u;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: the product
+    auto mma_round = [&](int buf, int s0) {
+#pragma unroll
+        for (int u = 0; u < LR_U; ++u) {
+            if (s0 + u < steps) {
+                const uint4 ah = *(const uint4*)(smem + (((s0 + u) * 2 + 0) * 64 + lane) * 16);
+                const uint4 al = *(const uint4*)(smem + (((s0 + u) * 2 + 1) * 64 + lane) * 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    mma16<bf16_t>(wv[buf][u][t], ah, acc[t]);
+                    mma16<bf16_t>(wv[buf][u][t], al, acc[t]);
+                }
+            }
+        }
+    };
+    for (int s0 = 0; s0 < steps; s0 += 2 * LR_U) {
+        if (s0 > 0 && s0 + LR_U < steps) load_round(1, s0 + LR_U);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_round(0, s0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s0 + LR_U < steps) {
+            if (s0 + 2 * LR_U < steps) load_round(0, s0 + 2 * LR_U);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_round(1, s0 + LR_U);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- epilogue: acc[t][r] = logit of row fr, column n0 + 16 t + 4 fg + r
+    const int m = fr;
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    bool bad = false;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + t * 16 + fg * 4;
+        if (p.logits && m < p.M && n < p.V) {
+            float* dst = p.logits + (long)m * p.ldl + n;
+            if (n + 3 < p.V && (p.ldl & 3) == 0) *(f32x4*)dst = acc[t];
+            else
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.V) dst[r] = acc[t][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[t][r];
+            if (n + r < p.V) {
+                bad |= (v != v);
+                if (v > best) { best = v; arg = n + r; }     // ascending n: the first maximum stays
+            }
+        }
+    }
+    if (!p.cand_val) return;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(arg, o, 64);
+        const int ob = __shfl_xor(bad ? 1 : 0, o, 64);
+        if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }
+        bad |= ob != 0;
+    }
+    if (fg == 0) { c_val[wave][fr] = bad ? __builtin_nanf("") : best; c_idx[wave][fr] = arg; }
+    __syncthreads();
+    if (tid < 16) {
+        float bv = c_val[0][tid];
+        int bi = c_idx[0][tid];
+        bool nb = bv != bv;
+#pragma unroll
+        for (int w = 1; w < LR_WAVES; ++w) {
+            const float ov = c_val[w][tid];
+            const int oi = c_idx[w][tid];
+            nb |= ov != ov;
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        const long at = (long)tid * gridDim.x + blockIdx.x;
+        p.cand_val[at] = nb ? __builtin_nanf("") : bv;
+        p.cand_idx[at] = bi;
+    }
+}
+
 template <typename T, typename TC> int launch_big(const GemmParams& p, hipStream_t s)
 {
     constexpr int KT = KB / (int)sizeof(T);
@@ -1374,6 +1552,27 @@ int uw_gemm_rows_hilo(const GemmParams& p, hipStream_t s)
         attr_set.mark();
     }
     hipLaunchKernelGGL(gemm_rows_hilo_kernel, dim3((p.N + HLN - 1) / HLN), dim3(512), lds, s, p);
+    UW_LAUNCH_CHECK();
+    return UW_OK;
+}
+
+int uw_logits_rows16_blocks(int V) { return (V + LR_COLS - 1) / LR_COLS; }
+
+int uw_logits_rows16(const LogitsRows16Params& p, hipStream_t s)
+{
+    UW_REQUIRE(p.x && p.gamma && p.beta && p.W && (p.logits || p.cand_val) && p.M > 0 && p.M <= 16 && p.V > 0 && p.d > 0 && p.d % 32 == 0 &&
+                   p.d <= 32 * LR_WAVES * LR_MAXS,
+               "logits_rows16: bad arguments (M=%d V=%d d=%d)", p.M, p.V, p.d);
+    UW_REQUIRE(!p.cand_val || p.cand_idx, "logits_rows16: candidate values without indices");
+    UW_REQUIRE(((uintptr_t)p.x % 16) == 0 && ((uintptr_t)p.W % 16) == 0 && ((uintptr_t)p.gamma % 16) == 0 && ((uintptr_t)p.beta % 16) == 0,
+               "logits_rows16: operands must be 16-byte aligned");
+    const size_t lds = (size_t)(p.d / 32) * 2048;
+    static PerDeviceFlag attr_set;
+    if (lds > 48 * 1024 && attr_set.pending()) {
+        UW_HIP_CHECK(hipFuncSetAttribute((const void*)logits_rows16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 32 * LR_WAVES * LR_MAXS * 64));
+        attr_set.mark();
+    }
+    hipLaunchKernelGGL(logits_rows16_kernel, dim3(uw_logits_rows16_blocks(p.V)), dim3(64 * LR_WAVES), lds, s, p);
     UW_LAUNCH_CHECK();
     return UW_OK;
 }

@@ -70,6 +70,22 @@ int uw_gemm_skinny(int dtype, int out_f32, const GemmParams& p, hipStream_t s);
 // bf16, M <= 128: C (f32) [M][N] = (A_hi + A_lo) . B^T with A rows stored [hi | lo] (lo starts K elements in, lda >= 2K),
 // B [N][K]; the tied output projection of a decode step.  Uses A, B, C, lda, ldb, ldc, M, N, K of the parameter block.
 int uw_gemm_rows_hilo(const GemmParams& p, hipStream_t s);
+// Tied output projection of a decode step for at most 16 windows, bf16 compute, in ONE launch: final LayerNorm of the
+// rows (held in LDS as hi + lo MFMA operand blocks), product with the [V][d] embedding streamed from memory once, and
+// per row the arg-max candidate of every 256-column workgroup, so that the greedy step need not scan the logits.
+struct LogitsRows16Params {
+    const float* x = nullptr;      // residual stream rows in the step's x layout (x_elem_offset<bf16_t>), one 16-row band
+    const float* gamma = nullptr;  // final LayerNorm scale and shift [d]
+    const float* beta = nullptr;
+    const void* W = nullptr;       // [V][d] bf16, fragment-major (uw_pack_frag): a wave fetches an operand block as 1 KiB of consecutive bytes
+    float* logits = nullptr;       // [M][ldl] or null (candidates only)
+    long ldl = 0;
+    float* cand_val = nullptr;     // [16][uw_logits_rows16_blocks(V)] row maximum per workgroup (NaN if the block holds one) or null
+    int32_t* cand_idx = nullptr;   // ... and its first index
+    int M = 0, V = 0, d = 0;
+};
+int uw_logits_rows16_blocks(int V);
+int uw_logits_rows16(const LogitsRows16Params& p, hipStream_t s);
 // row-major [R][K] (row stride ld) -> fragment-major, rows zero-padded to a multiple of 16
 int uw_pack_frag(int dtype, const void* src, long ld, void* dst, int R, int K, hipStream_t s);
 // row-major [R][K] (dtype) -> K-blocked [K / KT][R][KT], KT = 64 bytes of K (see GemmParams::kstep_a)
@@ -187,8 +203,11 @@ struct GreedyState {
 };
 // end of a greedy step: argmax of logits[b][0..V) per window, append / stop on eot / budget, classify text tokens,
 // advance pos, and write the chosen token's embedding as row b of the next step's residual stream x (x layout)
+// cand_val / cand_idx [B][n_cand] (optional): per row the arg-max candidates of its column blocks (uw_logits_rows16); the
+// logits are then not read
 int uw_greedy_next(int dtype, const GreedyState& st, const float* logits, long ld, int B, int V, int eot, int sot, int ts_begin,
-                   int ts_end, float* x, const float* tok_emb, const float* pos_emb, int d, hipStream_t s);
+                   int ts_end, float* x, const float* tok_emb, const float* pos_emb, int d, hipStream_t s,
+                   const float* cand_val = nullptr, const int32_t* cand_idx = nullptr, int n_cand = 0);
 
 // ---- uw_mel.hip -------------------------------------------------------------------------------
 struct MelTables;  // device tables owned by the context
