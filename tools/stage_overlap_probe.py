@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--dec-reps", type=int, default=2)
     ap.add_argument("--dec-priority", type=int, default=0, help="stream priority of the decode stage (-1 = high)")
     ap.add_argument("--enc-priority", type=int, default=0)
+    ap.add_argument("--enc-cus", type=int, default=0, help="> 0: the encoder stage's stream may use this many CUs, the decode stage's the rest")
+    ap.add_argument("--mask", choices=("low", "spread"), default="spread",
+                    help="low: the encoder gets mask bits 0..n-1; spread: n/8 bits out of every 32 (whatever the bit -> XCD map is, both see all of it)")
     args = ap.parse_args()
     import torch
     import bench as Bn
@@ -36,6 +39,23 @@ def main():
     n_samples = torch.full((B,), 480000, dtype=torch.int32, device=dev)
     ea, eb = (E.Engine(dims, sd, dtype="bf16", max_batch=B, align_heads=heads, device="cuda:0") for _ in range(2))
     sa, sb = torch.cuda.Stream(priority=args.enc_priority), torch.cuda.Stream(priority=args.dec_priority)
+    if args.enc_cus > 0:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        n = args.enc_cus
+        if args.mask == "low":
+            bits = [1 if i < n else 0 for i in range(256)]
+        else:
+            per = n // 8
+            bits = [1 if (i % 32) < per else 0 for i in range(256)]
+        def stream_for(bitlist):
+            words = (C.c_uint32 * 8)(*[sum(b << j for j, b in enumerate(bitlist[w * 32:(w + 1) * 32])) for w in range(8)])
+            h = C.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(C.byref(h), 8, words)
+            assert rc == 0, rc
+            return torch.cuda.ExternalStream(h.value)
+        sa, sb = stream_for(bits), stream_for([1 - b for b in bits])
+        print(f"encoder stage on {sum(bits)} CUs ({args.mask}), decode stage on {256 - sum(bits)}")
     print("priority range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "?")
 
     def enc_stage():

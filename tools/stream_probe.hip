@@ -73,7 +73,7 @@ int main()
     char* buf; unsigned* sink;
     if (hipMalloc(&buf, total) != hipSuccess || hipMalloc(&sink, 64 << 20) != hipSuccess) return 1;
     hipMemset(buf, 1, total);
-    for (int wgs : {256, 512, 1024, 2048}) {
+    for (int wgs : {32, 64, 128, 192, 256, 512, 1024, 2048}) {   // up to 256: one workgroup per CU on that many CUs
         for (int threads : {256, 512, 1024}) {
             if ((long)wgs * threads > 1024 * 1024) continue;
             run<0, 4>(buf, total, wgs, threads, sink);
