@@ -382,7 +382,8 @@ def main():
         secondary.append({"kernel": "decode step (all launches of one greedy step)", "bound": "hbm", "achieved": sb / (step_ms * 1e-3) / 1e9,
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "ms": step_ms,
                           "bytes_per_step": sb, "weight_bytes_per_step": w_dec, "steps_timed": sp["timed"],
-                          "weight_products_ms": gemm_ms, "launches_per_step": 8 * Ld + 3,
+                          "weight_products_ms": gemm_ms,
+                          "launches_per_step": 8 * Ld + (2 if (B <= 16 and args.dtype == "bf16") else 3),
                           "weight_products_achieved_GBs": w_dec / (gemm_ms * 1e-3) / 1e9})
     model_ms = path_roofline_ms(dims, B, P, args.gen, es)
     solo_ms = 1e3 * solo_elapsed / solo_steps
