@@ -431,7 +431,7 @@ int gemm(uw_ctx* c, const void* A, long lda, const void* Bw, long ldb, void* C, 
     return uw_gemm(c->dt, out_f32 ? 1 : 0, p, s);
 }
 
-// The product that follows a decode-step product in the chain: its weights are requested into L2 while this one runs
+// The product that follows a decode-step product in the chain: its weights are requested while this one runs
 // (GemmParams::pf).  ln: LayerNorm-fused form; otherwise the split-activation form.
 struct NextProduct {
     const void* w = nullptr;

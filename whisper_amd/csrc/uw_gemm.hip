@@ -970,8 +970,9 @@ constexpr int SK_ROUND_LN = 2;   // same for the LayerNorm-fused form, whose f32
 
 // Workgroup `i` of the extra ones a launch carries for GemmParams::pf: requests one dword of every 128-byte line of the
 // weight block that workgroup (i - pf_shift) of the following launch will read.  pf_shift makes the two land on the
-// same XCD (workgroups are dealt to the 8 XCDs round-robin by their linear index).  Nothing is kept: the lines stay
-// behind in that XCD's L2.  pf_never is always 0; the store under it only keeps the loads alive.
+// same XCD (workgroups are dealt to the 8 XCDs round-robin by their linear index).  Nothing is kept: the point is
+// that the lines have left HBM by the time the following launch asks for them.  pf_never is always 0; the store under
+// it only keeps the loads alive.
 template <typename T>
 __device__ __forceinline__ void prefetch_following_weights(const GemmParams& p, int i)
 {

@@ -52,9 +52,11 @@ struct GemmParams {
                         // C[m][n] at (n / 64) * c_group + m * ldc + (n % 64), ldc = 64 for a head-contiguous cache
     // Skinny form: fragment-major weights [pf_n][pf_k] of the product that FOLLOWS this one in the decode step (or null).
     // The launch then carries extra workgroups that only request those weights, each the block that the workgroup of the
-    // following launch scheduled on the same XCD will read, so that product finds its weights in that XCD's L2 instead of
-    // fetching them from HBM after it has started.  pf_cols: output columns per workgroup of the following launch
-    // (uw_gemm_skinny_block_columns).  pf_first / pf_shift / pf_never are filled in by the launcher.
+    // following launch scheduled on the same XCD will read, so that product does not start by waiting for HBM.  (The
+    // requested lines are found again on the memory side -- a product's L2 fetch count is the same with warm and with
+    // cold weights -- and fastest when the request came from the XCD that reads them.)  pf_cols: output columns per
+    // workgroup of the following launch (uw_gemm_skinny_block_columns).  pf_first / pf_shift / pf_never are filled in
+    // by the launcher.
     const void* pf = nullptr;
     int pf_n = 0, pf_k = 0, pf_cols = 0;
     int pf_first = 0x7fffffff, pf_shift = 0, pf_never = 0;   // pf_first: workgroups from this x index on compute nothing
