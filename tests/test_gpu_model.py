@@ -323,3 +323,34 @@ def test_one_launch_logits_agree_with_separate_kernels(micro):
         assert np.abs(got["0"][0] - got["1"][0]).max() < 2e-3, (B, np.abs(got["0"][0] - got["1"][0]).max())
         assert np.array_equal(got["0"][1], got["1"][1]) and np.array_equal(got["0"][2], got["1"][2]), B
         assert got["1"][2].max() > 0
+
+
+def test_row_split_merge_is_run_to_run_identical(micro):
+    """The row-split cross-attention merges its parts in whichever workgroup finishes last (tickets, device-scope loads
+    and stores).  The merge order is fixed, so repeated runs must give bit-identical tokens and attention rows, in both
+    compute types, whichever workgroup that was."""
+    import os
+    enc = micro["enc"]
+    sp = dict(MICRO_SPECIALS, sot=700)
+    prompts = [[824, 825, 826, 924], [823, 5, 6, 7, 824, 825, 826, 924, 11, 12]]
+    for dtype in ("f32", "bf16"):
+        os.environ["UW_DECODE_SPLIT"] = "8"
+        try:
+            eng = E.Engine(micro["dims"], micro["sd"], dtype=dtype, max_batch=2, align_heads=HEADS)
+        finally:
+            del os.environ["UW_DECODE_SPLIT"]
+        try:
+            eng.cross_kv(2, torch.from_numpy(enc).to(DEV))
+            first = None
+            for _ in range(40):
+                res = eng.decode_greedy(prompts, 30, sp["eot"], sp["sot"], sp["ts_begin"], sp["ts_end"])
+                nt = res["n_text"].cpu().numpy()
+                got = (res["new_tokens"].cpu().numpy(), nt, eng.attn_rows(2, int(nt.max())).cpu().numpy())
+                if first is None:
+                    first = got
+                    assert nt.max() > 0 and np.isfinite(got[2]).all()
+                else:
+                    for a, b in zip(first, got):
+                        assert np.array_equal(a, b), dtype
+        finally:
+            eng.close()
